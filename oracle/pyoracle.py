@@ -1,0 +1,378 @@
+"""ctypes view of oracle/liboracle.so — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; the product
+package (pathtracer_amd/) never does.  Layouts (ray 32 B, hit 16 B, node 8 B) are those of include/ptx.h.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liboracle.so")
+
+RAY_DTYPE = np.dtype([("o", "<f4", 3), ("tmin", "<f4"), ("d", "<f4", 3), ("tmax", "<f4")])
+HIT_DTYPE = np.dtype([("index", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
+NODE_DTYPE = np.dtype([("w0", "<u4"), ("w1", "<u4")])
+FMAX = np.finfo(np.float32).max
+MISS = 0xFFFFFFFF
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", HERE, "-s"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        L.orc_last_error.restype = C.c_char_p
+        for name in ("orc_tree_build", "orc_tree_from_flat", "orc_scene_load", "orc_scene_tree"):
+            getattr(L, name).restype = C.c_void_p
+        L.orc_render.restype = C.c_double
+        L.orc_bounce_rays.restype = C.c_size_t
+        L.orc_wrap01.restype = C.c_float
+        L.orc_wrap01.argtypes = [C.c_float]
+        _lib = L
+    return _lib
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def triangle_intersect(tri, ray, as_any=False):
+    """tri: 3x3, ray: (origin, direction).  Returns (t,u,v) float32 or None."""
+    out = np.zeros(3, np.float32)
+    r = _f(np.concatenate([ray[0], ray[1]]))
+    hit = lib().orc_triangle_intersect(_p(_f(tri).reshape(-1)), int(as_any), _p(r), _p(out))
+    return tuple(out) if hit else None
+
+
+def axial_axis(tri):
+    return lib().orc_axial_axis(_p(_f(tri).reshape(-1)))
+
+
+def axial_intersect_point(axis, dist, v, p):
+    out = np.zeros(2, np.float32)
+    hit = lib().orc_axial_intersect_point(axis, C.c_float(dist), _p(_f(v).reshape(-1)), _p(_f(p)), _p(out))
+    return tuple(out) if hit else None
+
+
+def aap_intersect(axis, dist, ray):
+    t = C.c_float()
+    r = _f(np.concatenate([ray[0], ray[1]]))
+    hit = lib().orc_aap_intersect(axis, C.c_float(dist), _p(r), C.byref(t))
+    return np.float32(t.value) if hit else None
+
+
+def clip_points(tri, aabb):
+    out = np.zeros((16, 3), np.float32)
+    n = lib().orc_clip_points(_p(_f(tri).reshape(-1)), _p(_f(aabb).reshape(-1)), _p(out), 16)
+    return out[:n]
+
+
+def clip_aabb(tri, aabb):
+    out = np.zeros(6, np.float32)
+    ok = lib().orc_clip_aabb(_p(_f(tri).reshape(-1)), _p(_f(aabb).reshape(-1)), _p(out))
+    return out.reshape(2, 3) if ok else None
+
+
+def bounding_box(tris):
+    t = _f(tris).reshape(-1, 9)
+    out = np.zeros(6, np.float32)
+    lib().orc_bounding_box(_p(t), len(t), _p(out))
+    return out.reshape(2, 3)
+
+
+def event_list(tris, axis):
+    t = _f(tris).reshape(-1, 9)
+    out = np.zeros((4 * len(t) + 4, 3), np.uint32)
+    n = lib().orc_event_list(_p(t), len(t), axis, _p(out), len(out))
+    kinds = {0: "end", 1: "planar", 2: "start"}
+    return [(kinds[int(k)], int(i), float(np.uint32(d).view(np.float32))) for i, d, k in out[:n]]
+
+
+def update_geometry_side(tris, axis, dist, side_right):
+    t = _f(tris).reshape(-1, 9)
+    out = np.zeros(len(t), np.uint8)
+    lib().orc_update_geometry_side(_p(t), len(t), axis, C.c_float(dist), int(side_right), _p(out))
+    return [["both", "left", "right"][i] for i in out]
+
+
+def make_rays(origins, directions, tmin=0.0, tmax=FMAX):
+    o = _f(origins).reshape(-1, 3)
+    r = np.zeros(len(o), RAY_DTYPE)
+    r["o"] = o
+    r["d"] = _f(directions).reshape(-1, 3)
+    r["tmin"] = tmin
+    r["tmax"] = tmax
+    return r
+
+
+class Tree:
+    """A pointer KdNode tree plus its triangles."""
+
+    def __init__(self, handle, owner=True):
+        if not handle:
+            raise RuntimeError(lib().orc_last_error().decode())
+        self.h = C.c_void_p(handle)
+
+    @classmethod
+    def build(cls, tris, sah=(1.0, 1.5, 0.8)):
+        t = _f(tris).reshape(-1, 9)
+        return cls(lib().orc_tree_build(_p(t), len(t), _p(_f(sah))))
+
+    @classmethod
+    def from_flat(cls, tris, nodes, leaf_idx, raw_triangles=False):
+        t = _f(tris).reshape(-1, 9)
+        nodes = np.ascontiguousarray(nodes, NODE_DTYPE)
+        leaf_idx = np.ascontiguousarray(leaf_idx, np.uint32)
+        return cls(lib().orc_tree_from_flat(_p(t), len(t), int(raw_triangles), _p(nodes), len(nodes), _p(leaf_idx)))
+
+    def __del__(self):
+        try:
+            lib().orc_tree_free(self.h)
+        except Exception:
+            pass
+
+    def string(self):
+        n = 1 << 16
+        while True:
+            buf = C.create_string_buffer(n)
+            r = lib().orc_tree_string(self.h, buf, C.c_size_t(n))
+            if r >= 0:
+                return buf.value.decode()
+            n = -r + 16
+
+    def stats(self):
+        out = np.zeros(6, np.uint64)
+        lib().orc_tree_stats(self.h, _p(out))
+        return dict(zip(["nodes", "leaves", "empty_leaves", "leaf_refs", "max_depth", "max_leaf"], map(int, out)))
+
+    def to_flat(self):
+        nn, nl = C.c_uint32(), C.c_uint32()
+        lib().orc_tree_to_flat(self.h, None, C.byref(nn), None, C.byref(nl))
+        nodes = np.zeros(nn.value, NODE_DTYPE)
+        leaf = np.zeros(max(nl.value, 1), np.uint32)
+        lib().orc_tree_to_flat(self.h, _p(nodes), C.byref(nn), _p(leaf), C.byref(nl))
+        return nodes, leaf[: nl.value]
+
+    def intersect(self, rays, threads=1, counters=False):
+        rays = np.ascontiguousarray(rays, RAY_DTYPE)
+        hits = np.zeros(len(rays), HIT_DTYPE)
+        ctr = np.zeros(3, np.uint64)
+        lib().orc_tree_intersect(self.h, _p(rays), C.c_size_t(len(rays)), _p(hits), _p(ctr) if counters else None, threads)
+        if counters:
+            return hits, dict(inner_nodes=int(ctr[0]), leaves=int(ctr[1]), tri_tests=int(ctr[2]))
+        return hits
+
+    def brute(self, rays, threads=1):
+        rays = np.ascontiguousarray(rays, RAY_DTYPE)
+        hits = np.zeros(len(rays), HIT_DTYPE)
+        lib().orc_brute_intersect(self.h, _p(rays), C.c_size_t(len(rays)), _p(hits), threads)
+        return hits
+
+
+def flat_leaf(indices, leaf_pool):
+    """helper for hand-written trees: returns a node spec consumed by flat_tree()."""
+    return ("leaf", list(indices))
+
+
+def flat_tree(spec):
+    """spec: ("leaf",[idx..]) | ("node", axis, distance, left_spec, right_spec) -> (nodes, leaf_idx) preorder."""
+    nodes, leaf = [], []
+
+    def rec(s):
+        me = len(nodes)
+        nodes.append([0, 0])
+        if s[0] == "leaf":
+            nodes[me] = [len(leaf), (len(s[1]) << 2) | 3]
+            leaf.extend(s[1])
+        else:
+            _, axis, dist, l, r = s
+            rec(l)
+            right = len(nodes)
+            nodes[me] = [int(np.float32(dist).view(np.uint32)), (right << 2) | axis]
+            rec(r)
+
+    rec(spec)
+    n = np.zeros(len(nodes), NODE_DTYPE)
+    for i, (a, b) in enumerate(nodes):
+        n[i] = (a, b)
+    return n, np.array(leaf, np.uint32)
+
+
+def tree_spec_string(spec):
+    """Canonical string of a hand-written tree spec, same format as Tree.string()."""
+    if spec[0] == "leaf":
+        return "[" + ",".join(str(i) for i in spec[1]) + "]"
+    _, axis, dist, l, r = spec
+    return "N(%s,%08x,%s,%s)" % ("XYZ"[axis], int(np.float32(dist).view(np.uint32)), tree_spec_string(l), tree_spec_string(r))
+
+
+def sample_refraction(wi, n, ior, diffuse, td, probability):
+    out = np.zeros(8, np.float32)
+    lib().orc_sample_refraction(_p(_f(wi)), _p(_f(n)), C.c_float(ior), _p(_f(diffuse)), _p(_f(td)), C.c_float(probability), _p(out))
+    return dict(is_delta=bool(out[0]), pdf=out[1], bsdf=out[2:5].copy(), wo=out[5:8].copy())
+
+
+def material_sample(color, f0, transmission, ior, wi, n, uv=(0, 0), mode=0, seed=0, dim=2):
+    out = np.zeros(8, np.float32)
+    mat = _f(list(color) + list(f0) + [transmission, ior])
+    lib().orc_material_sample(_p(mat), _p(_f(wi)), _p(_f(n)), _p(_f(uv)), mode, C.c_uint64(seed), dim, _p(out))
+    return dict(is_delta=bool(out[0]), pdf=out[1], bsdf=out[2:5].copy(), wo=out[5:8].copy())
+
+
+def material_from_mtl(kd, ks, ni, pm, tr):
+    out = np.zeros(8, np.float32)
+    lib().orc_material_from_mtl(_p(_f(kd)), _p(_f(ks)), C.c_float(ni), C.c_float(pm), C.c_float(tr), _p(out))
+    return out
+
+
+def sample_many(which, count, mode=0, seed=1):
+    width = {0: 2, 1: 3, 2: 2, 3: 3}[which]
+    out = np.zeros((count, width), np.float32)
+    lib().orc_sample_many(which, mode, C.c_uint64(seed), count, _p(out))
+    return out
+
+
+def texture_get(rgb, u, v):
+    rgb = _f(rgb)
+    out = np.zeros(3, np.float32)
+    lib().orc_texture_get(_p(rgb), rgb.shape[1], rgb.shape[0], C.c_float(u), C.c_float(v), _p(out))
+    return out
+
+
+def sincos(x):
+    x = _f(x)
+    s, c = np.zeros_like(x), np.zeros_like(x)
+    lib().orc_sincos(_p(x), len(x), _p(s), _p(c))
+    return s, c
+
+
+def to_rgb8(accum, iterations):
+    a = _f(accum)
+    out = np.zeros(a.shape, np.uint8)
+    lib().orc_to_rgb8(_p(a), C.c_size_t(a.size // 3), C.c_uint16(iterations & 0xFFFF), _p(out))
+    return out
+
+
+def _json_call(fn, text):
+    n = 1 << 20
+    while True:
+        buf = C.create_string_buffer(n)
+        r = fn(text.encode(), buf, C.c_size_t(n))
+        if r == -1:
+            raise ValueError(lib().orc_last_error().decode())
+        if r >= 0:
+            return json.loads(buf.value.decode())
+        n = -r + 16
+
+
+def parse_obj(text):
+    return _json_call(lib().orc_parse_obj_json, text)
+
+
+def parse_mtl(text):
+    return _json_call(lib().orc_parse_mtl_json, text)
+
+
+def srgb_to_linear_u8():
+    """sRGB EOTF for 8-bit texels (image crate convert_color_space to SRGB_LINEAR; parity unpinned)."""
+    c = np.arange(256, dtype=np.float64) / 255.0
+    lin = np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+    return lin.astype(np.float32)
+
+
+def load_texture_linear(path):
+    from PIL import Image
+
+    im = np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8)
+    return srgb_to_linear_u8()[im]
+
+
+class Scene:
+    """setup_scene of pathtracer-cli (main.rs:123-159) on the CPU restatement."""
+
+    def __init__(self, obj_path, sah=(1.0, 1.5, 0.8), max_bounces=10, load_textures=True):
+        h = lib().orc_scene_load(obj_path.encode(), _p(_f(sah)), max_bounces)
+        if not h:
+            raise RuntimeError(lib().orc_last_error().decode())
+        self.h = C.c_void_p(h)
+        self.path = obj_path
+        c = np.zeros(8, np.uint32)
+        lib().orc_scene_counts(self.h, _p(c))
+        self.counts = dict(zip(["triangles", "materials", "lights", "cameras", "vertices", "normals", "texcoords", "chunks"], map(int, c)))
+        self.textures = {}
+        if load_textures:
+            for m in range(self.counts["materials"]):
+                buf = C.create_string_buffer(1024)
+                lib().orc_scene_texture_name(self.h, m, buf, C.c_size_t(1024))
+                name = buf.value.decode()
+                if name:
+                    tex = load_texture_linear(os.path.join(os.path.dirname(obj_path), name))
+                    self.set_texture(m, tex)
+
+    def __del__(self):
+        try:
+            lib().orc_scene_free(self.h)
+        except Exception:
+            pass
+
+    def set_texture(self, material, rgb):
+        rgb = _f(rgb)
+        self.textures[material] = rgb
+        lib().orc_scene_set_texture(self.h, material, rgb.shape[1], rgb.shape[0], _p(rgb))
+
+    def export(self):
+        n = self.counts["triangles"]
+        tris = np.zeros((n, 9), np.float32)
+        normals = np.zeros((n, 9), np.float32)
+        uvs = np.zeros((n, 6), np.float32)
+        mats = np.zeros(n, np.uint32)
+        lib().orc_scene_export(self.h, _p(tris), _p(normals), _p(uvs), _p(mats))
+        materials = np.zeros((self.counts["materials"], 8), np.float32)
+        lights = np.zeros((max(self.counts["lights"], 1), 7), np.float32)
+        camera = np.zeros(10, np.float32)
+        lib().orc_scene_export_shading(self.h, _p(materials), _p(lights), _p(camera))
+        return dict(triangles=tris, normals=normals, texcoords=uvs, material_ids=mats, materials=materials,
+                    lights=lights[: self.counts["lights"]], camera=camera)
+
+    def tree(self):
+        return Tree(lib().orc_scene_tree(self.h))
+
+    def pinhole(self, w, h):
+        out = np.zeros(12, np.float32)
+        lib().orc_scene_pinhole(self.h, w, h, _p(out))
+        return out.reshape(4, 3)
+
+    def render(self, w, h, threads=1, iterations_per_thread=1, mode=1, seed=0, first_sample=0, accum=None, stats=False):
+        """render_parallel_iterations; returns (accum, seconds[, stats])."""
+        if accum is None:
+            accum = np.zeros((h, w, 3), np.float32)
+        st = np.zeros(8, np.uint64)
+        secs = lib().orc_render(self.h, w, h, threads, iterations_per_thread, mode, C.c_uint64(seed), first_sample, _p(accum), _p(st) if stats else None)
+        if stats:
+            keys = ["extend_rays", "shadow_rays", "extend_inner_nodes", "extend_tri_tests", "shadow_inner_nodes", "shadow_tri_tests", "extend_leaves", "shadow_leaves"]
+            return accum, secs, dict(zip(keys, map(int, st)))
+        return accum, secs
+
+    def bounce_rays(self, w, h, bounces=10, seed=0, threads=8):
+        fails = C.c_uint64()
+        cap = w * h * bounces * (1 + max(self.counts["lights"], 1))
+        rays = np.zeros(cap, RAY_DTYPE)
+        n = lib().orc_bounce_rays(self.h, w, h, bounces, C.c_uint64(seed), _p(rays), C.c_size_t(cap), C.byref(fails), threads)
+        return rays[:n].copy(), int(fails.value)
