@@ -1,0 +1,223 @@
+/* ptx.h — C ABI of libptx_mi355x.so: the MI355X (gfx950) implementation of daoo/pathtracer's render hot path.
+ *
+ * The reference is a Rust workspace without any FFI; its seams are ordinary Rust APIs.
+ * Every entry point below names the reference interface it replaces (file:line under the reference
+ * root).  A Rust `-sys` crate would bind exactly these symbols (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *  - every call returns int: 0 = ok, <0 = error class (PTX_E_*); ptx_last_error() gives the text
+ *    (thread-local).  No exception crosses the boundary.
+ *  - handles are opaque; the library copies what it needs and never keeps a caller pointer after return.
+ *  - one handle = one GPU (the current HIP device at create time).  Calls on one handle are not
+ *    re-entrant; different handles are independent.  Multi-GPU = one handle per device/process, sample
+ *    ranges sharded by the caller, accumulation buffers summed with RCCL (see ptx_render_device).
+ *  - "host" pointers are ordinary memory; "device" pointers are HIP device memory on the handle's GPU.
+ *  - there is no CPU fallback: without a usable HIP device every device call fails with PTX_E_HIP.
+ */
+#ifndef PTX_H
+#define PTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTX_OK 0
+#define PTX_E_ARG (-1)   /* bad argument / malformed scene description */
+#define PTX_E_HIP (-2)   /* HIP runtime error or no device */
+#define PTX_E_OOM (-3)   /* host or device allocation failed */
+#define PTX_E_IO (-4)    /* file could not be read / parsed / written */
+#define PTX_E_LIMIT (-5) /* size beyond a documented maximum */
+
+#define PTX_MISS 0xFFFFFFFFu
+#define PTX_MAX_LIGHTS 8
+#define PTX_MAX_DEPTH 25 /* kdtree/src/lib.rs:16 MAX_DEPTH */
+
+/* Ray + parametric range: `Ray{origin,direction}` (geometry/src/ray.rs:4-8) and the
+ * `RangeInclusive<f32>` argument of `KdNode::intersect` (kdtree/src/lib.rs:73-78).  32 bytes. */
+typedef struct ptx_ray {
+    float ox, oy, oz, tmin;
+    float dx, dy, dz, tmax;
+} ptx_ray;
+
+/* `Option<IndexedIntersection<TriangleIntersection>>` (geometry/src/geometry.rs:31-35,
+ * geometry/src/triangle.rs:108-113); index == PTX_MISS encodes None (then t=u=v=0).  16 bytes. */
+typedef struct ptx_hit {
+    uint32_t index;
+    float t, u, v;
+} ptx_hit;
+
+/* Flattened `KdNode` (kdtree/src/lib.rs:18-26), preorder, left child at i+1.  8 bytes.
+ *   inner: w0 = bits of plane.distance (f32), w1 = (index of right child << 2) | axis (0=X,1=Y,2=Z)
+ *   leaf : w0 = offset into the leaf index list,  w1 = (number of indices << 2) | 3            */
+typedef struct ptx_kdnode {
+    uint32_t w0, w1;
+} ptx_kdnode;
+
+/* `SahCost` (kdtree/src/sah.rs:52-56; defaults :122-130 = 1.0 / 1.5 / 0.8). */
+typedef struct ptx_sah_cost {
+    float traverse_cost, intersect_cost, empty_factor;
+} ptx_sah_cost;
+
+/* `Material` (tracing/src/material.rs:66-72): albedo colour or texture, Schlick f0, transmission, ior. */
+typedef struct ptx_material {
+    float albedo[3];
+    int32_t texture; /* index into textures, or -1 for AlbedoSource::Color */
+    float schlick_f0[3];
+    float transmission;
+    float ior;
+} ptx_material;
+
+/* `AlbedoSource::Texture(Rgb32FImage)` (tracing/src/material/albedo.rs:5-8): linear-light f32 RGB,
+ * row 0 = top row of the image file. */
+typedef struct ptx_texture {
+    uint32_t width, height;
+    const float* rgb; /* width*height*3 */
+} ptx_texture;
+
+/* `SphericalLight` (tracing/src/light.rs:26-30) — what every MTL light becomes (light.rs:79-89). */
+typedef struct ptx_light {
+    float center[3];
+    float intensity[3]; /* color * lightintensity */
+    float radius;
+} ptx_light;
+
+/* `Pinhole` (tracing/src/camera.rs:61-68): position, plane, dx, dy and the image size. */
+typedef struct ptx_pinhole {
+    float position[3], plane[3], dx[3], dy[3];
+    uint32_t width, height;
+} ptx_pinhole;
+
+/* Everything `Pathtracer<TriangleCollection>` owns (tracing/src/pathtracer.rs:14-19,
+ * tracing/src/collections.rs:32-37).  Arrays are caller-owned host memory, copied by ptx_scene_create.
+ * normals/texcoords/material_ids/materials may be NULL for an intersect-only scene. */
+typedef struct ptx_scene_desc {
+    const float* triangles; /* n_triangles * 9: v0 v1 v2 (AnyTriangle::from is applied inside) */
+    uint32_t n_triangles;
+    const ptx_kdnode* nodes;
+    uint32_t n_nodes;
+    const uint32_t* leaf_indices;
+    uint32_t n_leaf_indices;
+    const float* normals;         /* n_triangles * 9: n0 n1 n2 (tracing/src/properties.rs:10-14) */
+    const float* texcoords;       /* n_triangles * 6: uv0 uv1 uv2 */
+    const uint32_t* material_ids; /* n_triangles */
+    const ptx_material* materials;
+    uint32_t n_materials;
+    const ptx_texture* textures;
+    uint32_t n_textures;
+    const ptx_light* lights;
+    uint32_t n_lights; /* <= PTX_MAX_LIGHTS */
+    float environment[3]; /* pathtracer-cli/src/main.rs:155 uses 0.8,0.8,0.8 */
+    uint32_t max_bounces; /* `Pathtracer::max_bounces` (u8 in the reference) */
+} ptx_scene_desc;
+
+/* Counters accumulated since ptx_stats_reset.  Node / triangle counts are only collected when the
+ * scene was created with PTX_FLAG_COUNT_WORK (they cost atomics). */
+typedef struct ptx_counters {
+    uint64_t extend_rays, shadow_rays;
+    uint64_t extend_inner_nodes, extend_tri_tests;
+    uint64_t shadow_inner_nodes, shadow_tri_tests;
+    uint64_t samples; /* pixel samples completed */
+    double extend_ms, shadow_ms, shade_ms, generate_ms, total_ms; /* only with PTX_FLAG_TIME_KERNELS */
+} ptx_counters;
+
+typedef struct ptx_scene ptx_scene; /* opaque: device-resident scene (one GPU) */
+
+#define PTX_FLAG_COUNT_WORK 1u   /* count node visits / triangle tests in the traversal kernels */
+#define PTX_FLAG_TIME_KERNELS 2u /* bracket each kernel class with HIP events inside ptx_render */
+
+const char* ptx_last_error(void);
+const char* ptx_version(void);
+
+/* ---- host side: the parts that stay on the CPU ------------------------------------------------ */
+
+/* `build_kdtree(&[impl Geometry], &SahCost) -> KdNode` (kdtree/src/build.rs:33-41), emitted directly in
+ * the flattened layout.  Triangles are 9 floats each (v0 v1 v2); sah == NULL uses the defaults.  The
+ * returned tree owns its arrays; ptx_kdtree_view exposes them (valid until ptx_kdtree_free). */
+typedef struct ptx_kdtree ptx_kdtree;
+int ptx_kdtree_build(const float* triangles, uint32_t n_triangles, const ptx_sah_cost* sah,
+                     ptx_kdtree** out);
+int ptx_kdtree_view(const ptx_kdtree* tree, const ptx_kdnode** nodes, uint32_t* n_nodes,
+                    const uint32_t** leaf_indices, uint32_t* n_leaf_indices);
+void ptx_kdtree_free(ptx_kdtree* tree);
+
+/* `KdNode::intersect` for ONE ray on the host, over the flattened tree — the scalar form of the accel
+ * seam (kdtree/src/lib.rs:73-132), for callers that need an occasional query without a GPU round trip. */
+int ptx_kdtree_intersect_host(const float* triangles, uint32_t n_triangles, const ptx_kdnode* nodes,
+                              uint32_t n_nodes, const uint32_t* leaf_indices, const ptx_ray* ray,
+                              ptx_hit* hit);
+
+/* `Pinhole::new(Camera::new(position,target,up,fov), size)` (tracing/src/camera.rs:15-24, 71-85). */
+int ptx_pinhole_make(const float position[3], const float target[3], const float up[3],
+                     float fov_degrees, uint32_t width, uint32_t height, ptx_pinhole* out);
+
+/* `Material::load_from_mtl` arithmetic (tracing/src/material.rs:153-164) without the texture load. */
+int ptx_material_make(const float kd[3], const float ks[3], float ni, float pm, float transparency,
+                      int32_t texture, ptx_material* out);
+
+/* `ImageBuffer::to_rgb8(iterations as u16)` (tracing/src/image_buffer.rs:29-38; tracing/src/worker.rs:113
+ * truncates the iteration count to u16, kept). */
+int ptx_tonemap_rgb8(const float* accum_rgb, uint32_t width, uint32_t height, uint32_t iterations,
+                     uint8_t* out_rgb8);
+
+/* Loader: `read_obj_and_mtl_with_print_logging` + `from_wavefront` + `setup_scene`
+ * (wavefront/src/lib.rs:10-30, tracing/src/properties.rs:49-90, pathtracer-cli/src/main.rs:123-159)
+ * without the device upload.  The loaded scene owns its arrays; ptx_loaded_desc fills a ptx_scene_desc
+ * pointing into it (valid until ptx_loaded_free).  `verbose` prints the reference's "Loading ..." lines. */
+typedef struct ptx_loaded ptx_loaded;
+int ptx_load_obj(const char* obj_path, const ptx_sah_cost* sah, uint32_t max_bounces, int verbose,
+                 ptx_loaded** out);
+int ptx_loaded_desc(const ptx_loaded* loaded, ptx_scene_desc* desc);
+/* camera 0 of the MTL as 10 floats: position, target, up, fov (wavefront/src/mtl.rs:46-52) */
+int ptx_loaded_camera(const ptx_loaded* loaded, float out10[10]);
+void ptx_loaded_free(ptx_loaded* loaded);
+
+/* PNG in/out for the CLI (`image::open` in material.rs:143, `save_with_format` in
+ * pathtracer-cli/src/main.rs:186-188).  8-bit RGB/RGBA/grey non-interlaced only. */
+int ptx_png_write_rgb8(const char* path, const uint8_t* rgb, uint32_t width, uint32_t height);
+int ptx_png_read_linear(const char* path, float** rgb_out, uint32_t* width, uint32_t* height);
+void ptx_free(void* p);
+
+/* ---- device side: the hot path ----------------------------------------------------------------- */
+
+/* Upload a scene to the current HIP device. */
+int ptx_scene_create(const ptx_scene_desc* desc, uint32_t flags, ptx_scene** out);
+void ptx_scene_destroy(ptx_scene* scene);
+
+/* `KdNode::intersect(&self, geometries, ray, t_range)` in bulk (kdtree/src/lib.rs:73-78) =
+ * `GeometryCollection::intersect` (tracing/src/collections.rs:43-49).  Host buffers; synchronous. */
+int ptx_intersect_batch(ptx_scene* scene, const ptx_ray* rays, size_t n, ptx_hit* hits);
+/* Same with device-resident rays/hits, asynchronous on `stream` (a hipStream_t, NULL = default). */
+int ptx_intersect_batch_device(ptx_scene* scene, const ptx_ray* d_rays, size_t n, ptx_hit* d_hits,
+                               void* stream);
+/* Occlusion only: out[i] = 1 iff `intersect(ray, t_range).is_some()` — the only thing the integrator
+ * asks of a shadow ray (tracing/src/pathtracer.rs:72-78).  Device buffers. */
+int ptx_occluded_batch_device(ptx_scene* scene, const ptx_ray* d_rays, size_t n, uint8_t* d_out,
+                              void* stream);
+
+/* `render_parallel_iterations` minus the tonemap (tracing/src/worker.rs:84-119 over
+ * `Pathtracer::render_mut`, tracing/src/pathtracer.rs:131-141): renders global samples
+ * [first_sample, first_sample + sample_count) of every pixel with the counter-based sampler of
+ * ptx_sampling.h and ADDS the radiance sum into accum (width*height*3 floats, row-major, never
+ * cleared by the callee — image_buffer semantics).  progress (optional) is called after each
+ * completed batch with (samples completed so far, seconds since the call started, user) — the
+ * analogue of `tx.send(duration)` (worker.rs:47). */
+typedef void (*ptx_progress_cb)(uint32_t samples_done, double seconds, void* user);
+int ptx_render(ptx_scene* scene, const ptx_pinhole* camera, uint64_t seed, uint32_t first_sample,
+               uint32_t sample_count, float* accum_host, ptx_progress_cb progress, void* user);
+/* Same with a device-resident accumulation buffer, asynchronous on `stream`; this is what a
+ * multi-GPU driver calls before its RCCL reduce of the per-GPU buffers. */
+int ptx_render_device(ptx_scene* scene, const ptx_pinhole* camera, uint64_t seed, uint32_t first_sample,
+                      uint32_t sample_count, float* d_accum, void* stream);
+/* Samples kept in flight per launch batch (default chosen from the image size). */
+int ptx_set_batch_samples(ptx_scene* scene, uint32_t samples_per_batch);
+
+int ptx_stats(ptx_scene* scene, ptx_counters* out);
+int ptx_stats_reset(ptx_scene* scene);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTX_H */

@@ -1,0 +1,378 @@
+"""pathtracer_amd — host-side mirror of daoo/pathtracer's render seams over libptx_mi355x.so (gfx950).
+
+The reference is Rust; no Rust toolchain exists in the build image, so the host layer above the C ABI
+(include/ptx.h) is this thin ctypes binding plus the C++ CLIs under pathtracer_amd/cli.  Names follow the
+reference: `SahCost`, `build_kdtree`, `KdTree.intersect` (kdtree/src/lib.rs:73-78, build.rs:33),
+`Pinhole` (tracing/src/camera.rs:61-93), `Pathtracer.render` / `render_parallel_iterations`
+(tracing/src/pathtracer.rs:131-141, worker.rs:84-119), `ImageBuffer.to_rgb8` (image_buffer.rs:29-38).
+
+There is NO CPU fallback: every device call fails loudly when the HIP library or a GPU is missing.
+This package never imports anything from oracle/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libptx_mi355x.so")
+
+RAY_DTYPE = np.dtype([("o", "<f4", 3), ("tmin", "<f4"), ("d", "<f4", 3), ("tmax", "<f4")])
+HIT_DTYPE = np.dtype([("index", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
+NODE_DTYPE = np.dtype([("w0", "<u4"), ("w1", "<u4")])
+MISS = 0xFFFFFFFF
+FMAX = float(np.finfo(np.float32).max)
+MAX_LIGHTS = 8
+FLAG_COUNT_WORK = 1
+FLAG_TIME_KERNELS = 2
+
+
+class PtxError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("ptx error %d: %s" % (code, text))
+        self.code = code
+
+
+class SahCost(C.Structure):
+    """kdtree/src/sah.rs:52-56; defaults :122-130."""
+
+    _fields_ = [("traverse_cost", C.c_float), ("intersect_cost", C.c_float), ("empty_factor", C.c_float)]
+
+    def __init__(self, traverse_cost=1.0, intersect_cost=1.5, empty_factor=0.8):
+        super().__init__(traverse_cost, intersect_cost, empty_factor)
+
+
+class _Material(C.Structure):
+    _fields_ = [("albedo", C.c_float * 3), ("texture", C.c_int32), ("schlick_f0", C.c_float * 3),
+                ("transmission", C.c_float), ("ior", C.c_float)]
+
+
+class _Texture(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("rgb", C.POINTER(C.c_float))]
+
+
+class _Light(C.Structure):
+    _fields_ = [("center", C.c_float * 3), ("intensity", C.c_float * 3), ("radius", C.c_float)]
+
+
+class Pinhole(C.Structure):
+    """tracing/src/camera.rs:61-68."""
+
+    _fields_ = [("position", C.c_float * 3), ("plane", C.c_float * 3), ("dx", C.c_float * 3),
+                ("dy", C.c_float * 3), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+    @classmethod
+    def new(cls, position, target, up, fov_degrees, width, height):
+        """Pinhole::new(Camera::new(position, target, up, fov), size)."""
+        out = cls()
+        f3 = C.c_float * 3
+        _check(lib().ptx_pinhole_make(f3(*position), f3(*target), f3(*up), C.c_float(fov_degrees), width, height, C.byref(out)))
+        return out
+
+
+class _SceneDesc(C.Structure):
+    _fields_ = [
+        ("triangles", C.c_void_p), ("n_triangles", C.c_uint32),
+        ("nodes", C.c_void_p), ("n_nodes", C.c_uint32),
+        ("leaf_indices", C.c_void_p), ("n_leaf_indices", C.c_uint32),
+        ("normals", C.c_void_p), ("texcoords", C.c_void_p), ("material_ids", C.c_void_p),
+        ("materials", C.POINTER(_Material)), ("n_materials", C.c_uint32),
+        ("textures", C.POINTER(_Texture)), ("n_textures", C.c_uint32),
+        ("lights", C.POINTER(_Light)), ("n_lights", C.c_uint32),
+        ("environment", C.c_float * 3), ("max_bounces", C.c_uint32),
+    ]
+
+
+class Counters(C.Structure):
+    _fields_ = [("extend_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
+                ("extend_inner_nodes", C.c_uint64), ("extend_tri_tests", C.c_uint64),
+                ("shadow_inner_nodes", C.c_uint64), ("shadow_tri_tests", C.c_uint64),
+                ("samples", C.c_uint64),
+                ("extend_ms", C.c_double), ("shadow_ms", C.c_double), ("shade_ms", C.c_double),
+                ("generate_ms", C.c_double), ("total_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    """The HIP library; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PtxError(-2, "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(or make -C pathtracer_amd/csrc); there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.ptx_last_error.restype = C.c_char_p
+        L.ptx_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise PtxError(rc, lib().ptx_last_error().decode(errors="replace"))
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data) if a is not None and a.size else C.c_void_p(None)
+
+
+def version():
+    return lib().ptx_version().decode()
+
+
+def make_rays(origins, directions, tmin=0.0, tmax=FMAX):
+    o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+    r = np.zeros(len(o), RAY_DTYPE)
+    r["o"] = o
+    r["d"] = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
+    r["tmin"] = tmin
+    r["tmax"] = tmax
+    return r
+
+
+class KdTree:
+    """Flattened `KdNode` (8-byte preorder nodes + leaf index list) with its triangles."""
+
+    def __init__(self, triangles, nodes, leaf_indices):
+        self.triangles = np.ascontiguousarray(triangles, np.float32).reshape(-1, 9)
+        self.nodes = np.ascontiguousarray(nodes, NODE_DTYPE)
+        self.leaf_indices = np.ascontiguousarray(leaf_indices, np.uint32)
+
+    def intersect_host(self, origin, direction, t_range=(0.0, FMAX)):
+        """`KdNode::intersect` for one ray on the CPU (scalar form of the same traversal source)."""
+        ray = make_rays([origin], [direction], t_range[0], t_range[1])
+        hit = np.zeros(1, HIT_DTYPE)
+        _check(lib().ptx_kdtree_intersect_host(_ptr(self.triangles), len(self.triangles), _ptr(self.nodes), len(self.nodes),
+                                              _ptr(self.leaf_indices), _ptr(ray), _ptr(hit)))
+        return hit[0]
+
+    def upload(self, flags=0):
+        """Intersect-only device scene (the accel seam without shading data)."""
+        return DeviceScene.from_arrays(self.triangles, self.nodes, self.leaf_indices, flags=flags)
+
+
+def build_kdtree(triangles, sah=None):
+    """`build_kdtree(&[impl Geometry], &SahCost) -> KdNode` (kdtree/src/build.rs:33-41) on the host."""
+    t = np.ascontiguousarray(triangles, np.float32).reshape(-1, 9)
+    sah = sah or SahCost()
+    h = C.c_void_p()
+    _check(lib().ptx_kdtree_build(_ptr(t), len(t), C.byref(sah), C.byref(h)))
+    try:
+        pn, pl = C.c_void_p(), C.c_void_p()
+        nn, nl = C.c_uint32(), C.c_uint32()
+        _check(lib().ptx_kdtree_view(h, C.byref(pn), C.byref(nn), C.byref(pl), C.byref(nl)))
+        nodes = np.frombuffer(C.string_at(pn, nn.value * 8), NODE_DTYPE).copy()
+        leaf = np.frombuffer(C.string_at(pl, nl.value * 4), np.uint32).copy() if nl.value else np.zeros(0, np.uint32)
+    finally:
+        lib().ptx_kdtree_free(h)
+    return KdTree(t, nodes, leaf)
+
+
+class LoadedScene:
+    """`setup_scene` (pathtracer-cli/src/main.rs:123-159): OBJ + MTL + KD-tree, still on the host."""
+
+    def __init__(self, obj_path, sah=None, max_bounces=10, verbose=False):
+        sah = sah or SahCost()
+        self._h = C.c_void_p()
+        _check(lib().ptx_load_obj(os.fsencode(obj_path), C.byref(sah), max_bounces, int(verbose), C.byref(self._h)))
+        self.desc = _SceneDesc()
+        _check(lib().ptx_loaded_desc(self._h, C.byref(self.desc)))
+        cam = (C.c_float * 10)()
+        _check(lib().ptx_loaded_camera(self._h, cam))
+        self.camera = np.array(cam[:], np.float32)
+        self.path = obj_path
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().ptx_loaded_free(self._h)
+        except Exception:
+            pass
+
+    def _view(self, ptr, count, dtype):
+        if not ptr or not count:
+            return np.zeros(0, dtype)
+        return np.frombuffer(C.string_at(ptr, count * np.dtype(dtype).itemsize), dtype).copy()
+
+    @property
+    def n_triangles(self):
+        return self.desc.n_triangles
+
+    def arrays(self):
+        d = self.desc
+        return dict(
+            triangles=self._view(d.triangles, d.n_triangles * 9, np.float32).reshape(-1, 9),
+            normals=self._view(d.normals, d.n_triangles * 9, np.float32).reshape(-1, 9),
+            texcoords=self._view(d.texcoords, d.n_triangles * 6, np.float32).reshape(-1, 6),
+            material_ids=self._view(d.material_ids, d.n_triangles, np.uint32),
+            nodes=self._view(d.nodes, d.n_nodes, NODE_DTYPE),
+            leaf_indices=self._view(d.leaf_indices, d.n_leaf_indices, np.uint32),
+            materials=np.array([[*m.albedo, *m.schlick_f0, m.transmission, m.ior] for m in (d.materials[i] for i in range(d.n_materials))], np.float32).reshape(-1, 8),
+            material_textures=[d.materials[i].texture for i in range(d.n_materials)],
+            lights=np.array([[*l.center, *l.intensity, l.radius] for l in (d.lights[i] for i in range(d.n_lights))], np.float32).reshape(-1, 7),
+        )
+
+    def texture(self, index):
+        t = self.desc.textures[index]
+        n = t.width * t.height * 3
+        return np.frombuffer(C.string_at(t.rgb, n * 4), np.float32).reshape(t.height, t.width, 3).copy()
+
+    def kdtree(self):
+        a = self.arrays()
+        return KdTree(a["triangles"], a["nodes"], a["leaf_indices"])
+
+    def pinhole(self, width, height):
+        """`Pinhole::new(mtl.cameras[0].clone().into(), size)` (main.rs:137)."""
+        c = self.camera
+        return Pinhole.new(c[0:3], c[3:6], c[6:9], float(c[9]), width, height)
+
+    def upload(self, flags=0):
+        return DeviceScene(self.desc, flags=flags, keepalive=self)
+
+
+class DeviceScene:
+    """A scene resident on the current HIP device: the `TriangleCollection` + `Pathtracer` state."""
+
+    def __init__(self, desc, flags=0, keepalive=None):
+        self._h = C.c_void_p()
+        self._keep = keepalive
+        _check(lib().ptx_scene_create(C.byref(desc), flags, C.byref(self._h)))
+        self.max_bounces = desc.max_bounces
+        self.n_lights = desc.n_lights
+
+    @classmethod
+    def from_arrays(cls, triangles, nodes, leaf_indices, normals=None, texcoords=None, material_ids=None,
+                    materials=None, material_textures=None, textures=None, lights=None,
+                    environment=(0.8, 0.8, 0.8), max_bounces=10, flags=0):
+        keep = {}
+        d = _SceneDesc()
+        keep["tri"] = t = np.ascontiguousarray(triangles, np.float32).reshape(-1, 9)
+        keep["nodes"] = n = np.ascontiguousarray(nodes, NODE_DTYPE)
+        keep["leaf"] = l = np.ascontiguousarray(leaf_indices, np.uint32)
+        d.triangles, d.n_triangles = _ptr(t), len(t)
+        d.nodes, d.n_nodes = _ptr(n), len(n)
+        d.leaf_indices, d.n_leaf_indices = _ptr(l), len(l)
+        if normals is not None:
+            keep["nrm"] = a = np.ascontiguousarray(normals, np.float32).reshape(-1, 9)
+            keep["uv"] = b = np.ascontiguousarray(texcoords, np.float32).reshape(-1, 6)
+            keep["mid"] = c = np.ascontiguousarray(material_ids, np.uint32)
+            if not (len(a) == len(b) == len(c) == len(t)):
+                raise PtxError(-1, "per-triangle arrays must all have n_triangles rows")
+            d.normals, d.texcoords, d.material_ids = _ptr(a), _ptr(b), _ptr(c)
+            textures = textures or []
+            keep["texdata"] = td = [np.ascontiguousarray(x, np.float32) for x in textures]
+            keep["tex"] = tx = (_Texture * max(len(td), 1))()
+            for i, x in enumerate(td):
+                tx[i].width, tx[i].height = x.shape[1], x.shape[0]
+                tx[i].rgb = x.ctypes.data_as(C.POINTER(C.c_float))
+            d.textures, d.n_textures = tx, len(td)
+            mats = np.asarray(materials, np.float32).reshape(-1, 8)
+            keep["mat"] = ma = (_Material * max(len(mats), 1))()
+            for i, m in enumerate(mats):
+                ma[i].albedo = (C.c_float * 3)(*m[0:3])
+                ma[i].schlick_f0 = (C.c_float * 3)(*m[3:6])
+                ma[i].transmission, ma[i].ior = float(m[6]), float(m[7])
+                ma[i].texture = -1 if material_textures is None else int(material_textures[i])
+            d.materials, d.n_materials = ma, len(mats)
+        lights = np.zeros((0, 7), np.float32) if lights is None else np.asarray(lights, np.float32).reshape(-1, 7)
+        keep["lights"] = li = (_Light * max(len(lights), 1))()
+        for i, x in enumerate(lights[:MAX_LIGHTS]):
+            li[i].center = (C.c_float * 3)(*x[0:3])
+            li[i].intensity = (C.c_float * 3)(*x[3:6])
+            li[i].radius = float(x[6])
+        d.lights, d.n_lights = li, len(lights)
+        d.environment = (C.c_float * 3)(*environment)
+        d.max_bounces = max_bounces
+        return cls(d, flags=flags, keepalive=keep)
+
+    def close(self):
+        if self._h:
+            lib().ptx_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- accel seam: KdNode::intersect in bulk ------------------------------------------------------
+    def intersect(self, rays):
+        """Host arrays in, host arrays out (copies over PCIe)."""
+        rays = np.ascontiguousarray(rays, RAY_DTYPE)
+        hits = np.zeros(len(rays), HIT_DTYPE)
+        _check(lib().ptx_intersect_batch(self._h, _ptr(rays), C.c_size_t(len(rays)), _ptr(hits)))
+        return hits
+
+    def intersect_device(self, d_rays_ptr, n, d_hits_ptr, stream=None):
+        _check(lib().ptx_intersect_batch_device(self._h, C.c_void_p(d_rays_ptr), C.c_size_t(n), C.c_void_p(d_hits_ptr), C.c_void_p(stream)))
+
+    def occluded_device(self, d_rays_ptr, n, d_out_ptr, stream=None):
+        _check(lib().ptx_occluded_batch_device(self._h, C.c_void_p(d_rays_ptr), C.c_size_t(n), C.c_void_p(d_out_ptr), C.c_void_p(stream)))
+
+    # ---- integrator seam ----------------------------------------------------------------------------
+    def set_batch_samples(self, n):
+        _check(lib().ptx_set_batch_samples(self._h, n))
+
+    def render(self, pinhole, sample_count, seed=0, first_sample=0, accum=None, progress=None):
+        """Adds samples [first_sample, first_sample+sample_count) into accum (H x W x 3 float32)."""
+        if accum is None:
+            accum = np.zeros((pinhole.height, pinhole.width, 3), np.float32)
+        assert accum.dtype == np.float32 and accum.flags.c_contiguous and accum.size == pinhole.width * pinhole.height * 3
+        cb_t = C.CFUNCTYPE(None, C.c_uint32, C.c_double, C.c_void_p)
+        cb = cb_t(lambda done, secs, _u: progress(done, secs)) if progress else C.cast(None, cb_t)
+        _check(lib().ptx_render(self._h, C.byref(pinhole), C.c_uint64(seed), first_sample, sample_count, _ptr(accum), cb, None))
+        return accum
+
+    def render_device(self, pinhole, sample_count, d_accum_ptr, seed=0, first_sample=0, stream=None):
+        _check(lib().ptx_render_device(self._h, C.byref(pinhole), C.c_uint64(seed), first_sample, sample_count,
+                                       C.c_void_p(d_accum_ptr), C.c_void_p(stream)))
+
+    def stats(self):
+        c = Counters()
+        _check(lib().ptx_stats(self._h, C.byref(c)))
+        return c.as_dict()
+
+    def stats_reset(self):
+        _check(lib().ptx_stats_reset(self._h))
+
+
+def to_rgb8(accum, iterations):
+    """`ImageBuffer::to_rgb8(iterations as u16)`."""
+    a = np.ascontiguousarray(accum, np.float32)
+    h, w = a.shape[0], a.shape[1]
+    out = np.zeros((h, w, 3), np.uint8)
+    _check(lib().ptx_tonemap_rgb8(_ptr(a), w, h, iterations, _ptr(out)))
+    return out
+
+
+def write_png(path, rgb8):
+    a = np.ascontiguousarray(rgb8, np.uint8)
+    _check(lib().ptx_png_write_rgb8(os.fsencode(path), _ptr(a), a.shape[1], a.shape[0]))
+
+
+def read_png_linear(path):
+    p = C.POINTER(C.c_float)()
+    w, h = C.c_uint32(), C.c_uint32()
+    _check(lib().ptx_png_read_linear(os.fsencode(path), C.byref(p), C.byref(w), C.byref(h)))
+    try:
+        return np.frombuffer(C.string_at(p, w.value * h.value * 12), np.float32).reshape(h.value, w.value, 3).copy()
+    finally:
+        lib().ptx_free(p)
+
+
+def render_parallel_iterations(scene, pinhole, threads, iterations_per_thread, seed=0, progress=None):
+    """`render_parallel_iterations` (tracing/src/worker.rs:84-119): threads x iterations_per_thread
+    full-frame samples on ONE GPU; returns (seconds, rgb8 image).  The GPU plays every thread."""
+    import time
+
+    total = threads * iterations_per_thread
+    t0 = time.perf_counter()
+    accum = scene.render(pinhole, total, seed=seed, progress=progress)
+    secs = time.perf_counter() - t0
+    return secs, to_rgb8(accum, total)

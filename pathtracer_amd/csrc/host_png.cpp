@@ -1,0 +1,169 @@
+// host_png.cpp — minimal PNG reader/writer over zlib for the CLI and the OBJ loader.
+//
+// Replaces the reference's use of the `image` crate: `image::open` + `convert_color_space(SRGB_LINEAR)`
+// for textures (tracing/src/material.rs:143-151) and `save_with_format(.., Png)` for the result
+// (pathtracer-cli/src/main.rs:186-188).  8-bit, non-interlaced grey / grey+alpha / RGB / RGBA / palette.
+// sRGB decode is the piecewise IEC 61966-2-1 EOTF evaluated in double and rounded once to f32 per
+// 8-bit code (the `image`/`moxcms` arithmetic is not vendored: parity unpinned, tolerance-based).
+#include <zlib.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "host_internal.hpp"
+
+namespace {
+
+uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+void put32(std::vector<uint8_t>& v, uint32_t x) {
+    v.push_back((uint8_t)(x >> 24));
+    v.push_back((uint8_t)(x >> 16));
+    v.push_back((uint8_t)(x >> 8));
+    v.push_back((uint8_t)x);
+}
+void chunk(std::vector<uint8_t>& out, const char* type, const uint8_t* data, size_t n) {
+    put32(out, (uint32_t)n);
+    size_t start = out.size();
+    out.insert(out.end(), type, type + 4);
+    if (n) out.insert(out.end(), data, data + n);
+    put32(out, (uint32_t)crc32(0, out.data() + start, (uInt)(n + 4)));
+}
+int paeth(int a, int b, int c) {
+    int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+}  // namespace
+
+using namespace ptx;
+
+extern "C" {
+
+int ptx_png_write_rgb8(const char* path, const uint8_t* rgb, uint32_t width, uint32_t height) {
+    if (!path || !rgb || !width || !height) return fail(PTX_E_ARG, "ptx_png_write_rgb8: bad argument");
+    std::vector<uint8_t> raw;
+    raw.reserve(((size_t)width * 3 + 1) * height);
+    for (uint32_t y = 0; y < height; ++y) {
+        raw.push_back(0);  // filter: none
+        raw.insert(raw.end(), rgb + (size_t)y * width * 3, rgb + (size_t)(y + 1) * width * 3);
+    }
+    uLongf zn = compressBound((uLong)raw.size());
+    std::vector<uint8_t> z(zn);
+    if (compress2(z.data(), &zn, raw.data(), (uLong)raw.size(), 6) != Z_OK) return fail(PTX_E_IO, "zlib compress failed");
+    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    std::vector<uint8_t> ihdr;
+    put32(ihdr, width);
+    put32(ihdr, height);
+    const uint8_t tail[5] = {8, 2, 0, 0, 0};  // 8-bit RGB
+    ihdr.insert(ihdr.end(), tail, tail + 5);
+    chunk(out, "IHDR", ihdr.data(), ihdr.size());
+    chunk(out, "IDAT", z.data(), zn);
+    chunk(out, "IEND", nullptr, 0);
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(PTX_E_IO, std::string("cannot create ") + path);
+    size_t w = fwrite(out.data(), 1, out.size(), f);
+    fclose(f);
+    return w == out.size() ? PTX_OK : fail(PTX_E_IO, std::string("short write to ") + path);
+}
+
+int ptx_png_read_linear(const char* path, float** rgb_out, uint32_t* width, uint32_t* height) {
+    if (!path || !rgb_out || !width || !height) return fail(PTX_E_ARG, "ptx_png_read_linear: null argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(PTX_E_IO, std::string("cannot open ") + path);
+    std::vector<uint8_t> file;
+    uint8_t buf[1 << 16];
+    size_t got;
+    while ((got = fread(buf, 1, sizeof buf, f)) > 0) file.insert(file.end(), buf, buf + got);
+    fclose(f);
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    if (file.size() < 8 || memcmp(file.data(), sig, 8) != 0) return fail(PTX_E_IO, std::string(path) + ": not a PNG");
+    uint32_t w = 0, h = 0;
+    int depth = 0, ctype = 0, interlace = 0;
+    std::vector<uint8_t> idat, plte;
+    size_t pos = 8;
+    while (pos + 12 <= file.size()) {
+        uint32_t n = be32(&file[pos]);
+        if (pos + 12 + (size_t)n > file.size()) return fail(PTX_E_IO, std::string(path) + ": truncated chunk");
+        const uint8_t* type = &file[pos + 4];
+        const uint8_t* data = &file[pos + 8];
+        if (!memcmp(type, "IHDR", 4) && n >= 13) {
+            w = be32(data);
+            h = be32(data + 4);
+            depth = data[8];
+            ctype = data[9];
+            interlace = data[12];
+        } else if (!memcmp(type, "PLTE", 4)) {
+            plte.assign(data, data + n);
+        } else if (!memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), data, data + n);
+        } else if (!memcmp(type, "IEND", 4)) {
+            break;
+        }
+        pos += 12 + (size_t)n;
+    }
+    int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!w || !h || depth != 8 || !channels || interlace)
+        return fail(PTX_E_IO, std::string(path) + ": unsupported PNG (need 8-bit, non-interlaced)");
+    if ((uint64_t)w * h > (1ull << 28)) return fail(PTX_E_LIMIT, std::string(path) + ": image too large");
+    size_t stride = (size_t)w * channels;
+    std::vector<uint8_t> raw((stride + 1) * h);
+    uLongf rawn = (uLongf)raw.size();
+    if (uncompress(raw.data(), &rawn, idat.data(), (uLong)idat.size()) != Z_OK || rawn != raw.size())
+        return fail(PTX_E_IO, std::string(path) + ": inflate failed");
+    std::vector<uint8_t> img(stride * h);
+    for (uint32_t y = 0; y < h; ++y) {
+        const uint8_t* in = &raw[(stride + 1) * y];
+        uint8_t* cur = &img[stride * y];
+        const uint8_t* up = y ? &img[stride * (y - 1)] : nullptr;
+        int filter = in[0];
+        for (size_t x = 0; x < stride; ++x) {
+            int a = x >= (size_t)channels ? cur[x - channels] : 0;
+            int b = up ? up[x] : 0;
+            int c = (up && x >= (size_t)channels) ? up[x - channels] : 0;
+            int v = in[1 + x];
+            switch (filter) {
+                case 0: break;
+                case 1: v += a; break;
+                case 2: v += b; break;
+                case 3: v += (a + b) >> 1; break;
+                case 4: v += paeth(a, b, c); break;
+                default: return fail(PTX_E_IO, std::string(path) + ": bad PNG filter");
+            }
+            cur[x] = (uint8_t)v;
+        }
+    }
+    float lut[256];
+    for (int i = 0; i < 256; ++i) {
+        double c = i / 255.0;
+        lut[i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
+    }
+    float* out = (float*)malloc((size_t)w * h * 3 * sizeof(float));
+    if (!out) return fail(PTX_E_OOM, "ptx_png_read_linear: out of memory");
+    for (size_t i = 0; i < (size_t)w * h; ++i) {
+        uint8_t r, g, b;
+        const uint8_t* p = &img[i * channels];
+        if (ctype == 3) {
+            if ((size_t)p[0] * 3 + 2 >= plte.size()) {
+                free(out);
+                return fail(PTX_E_IO, std::string(path) + ": palette index out of range");
+            }
+            r = plte[p[0] * 3], g = plte[p[0] * 3 + 1], b = plte[p[0] * 3 + 2];
+        } else if (channels <= 2) {
+            r = g = b = p[0];
+        } else {
+            r = p[0], g = p[1], b = p[2];
+        }
+        out[3 * i] = lut[r];
+        out[3 * i + 1] = lut[g];
+        out[3 * i + 2] = lut[b];
+    }
+    *rgb_out = out;
+    *width = w;
+    *height = h;
+    return PTX_OK;
+}
+
+}  // extern "C"

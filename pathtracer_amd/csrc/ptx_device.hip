@@ -1,0 +1,938 @@
+// ptx_device.hip — gfx950 kernels and the device half of the C ABI (include/ptx.h).
+//
+// Wavefront path tracer: generate → [extend → shade → shadow] × max_bounces → accumulate.
+//   generate    one path per (pixel, sample) slot: jittered pinhole ray        pathtracer.rs:113-117, camera.rs:88-93
+//   extend      nearest hit through the flattened KD-tree                       kdtree/src/lib.rs:73-132
+//   shade       everything between the two intersect calls of trace_ray         pathtracer.rs:44-108, material.rs:167-191,
+//               + next-ray emission and shadow-ray emission (queues compacted     light.rs:61-76, properties.rs:24-31
+//               with wave ballot + LDS prefix sum, one atomic per workgroup)
+//   shadow      occlusion of the light samples, radiance += T * sum(c_l)        pathtracer.rs:68-86
+//   accumulate  image += per-path radiance, samples added in index order        pathtracer.rs:138-140
+// A path's radiance is owned by its slot (no float atomics anywhere), so an image is bit-reproducible
+// and independent of queue order.  All arithmetic is IEEE f32 without contraction; random numbers and
+// sin/cos come from include/ptx_sampling.h.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <chrono>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/ptx.h"
+#include "../../include/ptx_sampling.h"
+#include "host_internal.hpp"
+#include "traverse.hpp"
+
+using namespace ptx;
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int WAVES = BLOCK / 64;
+
+struct DevMaterial {
+    float albedo[3];
+    int32_t texture;
+    float f0[3];
+    float transmission;
+    float ior;
+    uint32_t tex_w, tex_h;
+    const float* tex_rgb;
+};
+
+struct DevScene {
+    const ptx_kdnode* nodes;
+    const uint32_t* leaf_idx;
+    const TriRec* tris;
+    const float4* props;  // 4 x float4 per triangle: n0 n1 n2 (9) uv0 uv1 uv2 (6) material id (1)
+    const DevMaterial* materials;
+    ptx_light lights[PTX_MAX_LIGHTS];
+    uint32_t n_lights;
+    float env[3];
+    uint32_t max_bounces;
+};
+
+struct RenderState {
+    ptx_ray* rays[2];
+    uint32_t* pids[2];
+    ptx_hit* hits;
+    float4* transport;
+    float4* radiance;
+    float4* sh_origin;   // {point_above.xyz, bits(pid)}
+    float4* sh_T;        // {transport before this bounce's update, 0}
+    float4* sh_dir;      // [i * n_lights + l] {target - origin, 0}
+    float4* sh_contrib;  // [i * n_lights + l] {bsdf * emitted * |cos|, 0}
+    uint32_t* ext_counts;  // [max_bounces + 1]
+    uint32_t* sh_counts;   // [max_bounces]
+    unsigned long long* totals;  // extend rays, shadow rays, ext inner, ext tris, sh inner, sh tris
+    ptx_pinhole cam;
+    uint64_t seed;
+    uint32_t n_pixels, n_samples, first_sample;
+};
+
+// ------------------------------------------------------------------------------------------ helpers
+struct V3 {
+    float x, y, z;
+};
+__device__ inline V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ inline V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ inline V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ inline V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+__device__ inline V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ inline V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+__device__ inline V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+__device__ inline V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+__device__ inline V3 operator-(float s, V3 a) { return v3(s - a.x, s - a.y, s - a.z); }
+__device__ inline float dot(V3 a, V3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
+__device__ inline V3 cross(V3 a, V3 b) {
+    return v3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
+}
+__device__ inline V3 normalize(V3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+__device__ inline float luminance(V3 c) { return 0.2126f * c.x + 0.7152f * c.y + 0.0722f * c.z; }
+
+// Stable compaction slot for the lanes of a workgroup that raise `flag`: wave ballot + prefix over the
+// waves in LDS + ONE atomic on the queue counter per workgroup.  All threads of the block must call.
+__device__ inline uint32_t block_slot(bool flag, uint32_t* counter, uint32_t* lds /* WAVES + 1 */) {
+    const unsigned long long ballot = __ballot(flag);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t before = __popcll(ballot & ((1ull << lane) - 1ull));
+    if (lane == 0) lds[wave] = (uint32_t)__popcll(ballot);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < WAVES; ++w) {
+            uint32_t c = lds[w];
+            lds[w] = total;
+            total += c;
+        }
+        lds[WAVES] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    const uint32_t slot = lds[WAVES] + lds[wave] + before;
+    __syncthreads();  // lds is reused by the next call
+    return slot;
+}
+
+__device__ inline void wave_add(unsigned long long* dst, uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63u) == 0 && v) atomicAdd(dst, (unsigned long long)v);
+}
+
+// ------------------------------------------------------------------------------------------ kernels
+template <bool ANY, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_traverse(const ptx_kdnode* __restrict__ nodes,
+                                                    const uint32_t* __restrict__ leaf_idx,
+                                                    const TriRec* __restrict__ tris,
+                                                    const ptx_ray* __restrict__ rays,
+                                                    const uint32_t* __restrict__ count_ptr, uint32_t fixed_count,
+                                                    ptx_hit* __restrict__ hits, uint8_t* __restrict__ occluded,
+                                                    unsigned long long* work /* [2]: inner, tris */) {
+    const uint32_t count = count_ptr ? *count_ptr : fixed_count;
+    WorkCount wc{0, 0};
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
+        const float4 a = reinterpret_cast<const float4*>(rays)[2 * (size_t)i];
+        const float4 b = reinterpret_cast<const float4*>(rays)[2 * (size_t)i + 1];
+        ptx_hit h;
+        kd_traverse<ANY, COUNT>(nodes, leaf_idx, tris, a.x, a.y, a.z, b.x, b.y, b.z, a.w, b.w, h, wc);
+        if (ANY) {
+            occluded[i] = h.index != PTX_MISS ? 1 : 0;
+        } else {
+            uint4 o;
+            o.x = h.index;
+            o.y = f2u(h.t);
+            o.z = f2u(h.u);
+            o.w = f2u(h.v);
+            reinterpret_cast<uint4*>(hits)[i] = o;
+        }
+    }
+    if (COUNT) {
+        wave_add(&work[0], wc.inner);
+        wave_add(&work[1], wc.tris);
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_generate(RenderState st) {
+    const uint32_t total = st.n_pixels * st.n_samples;
+    for (uint32_t pid = blockIdx.x * BLOCK + threadIdx.x; pid < total; pid += gridDim.x * BLOCK) {
+        const uint32_t pixel = pid % st.n_pixels, s = pid / st.n_pixels;
+        const uint32_t px = pixel % st.cam.width, py = pixel / st.cam.width;
+        const uint64_t key = ptx_path_key(st.seed, pixel, st.first_sample + s);
+        // sample_ray_for_pixel (pathtracer.rs:113-117) + Pinhole::ray (camera.rs:88-93)
+        const float cx = (float)px + ptx_u01(key, 0), cy = (float)py + ptx_u01(key, 1);
+        const float u = cx / (float)st.cam.width, v = cy / (float)st.cam.height;
+        ptx_ray r;
+        r.ox = st.cam.position[0];
+        r.oy = st.cam.position[1];
+        r.oz = st.cam.position[2];
+        r.tmin = 0.0f;
+        r.dx = st.cam.plane[0] + u * st.cam.dx[0] + v * st.cam.dy[0];
+        r.dy = st.cam.plane[1] + u * st.cam.dx[1] + v * st.cam.dy[1];
+        r.dz = st.cam.plane[2] + u * st.cam.dx[2] + v * st.cam.dy[2];
+        r.tmax = 3.402823466e+38f;
+        reinterpret_cast<float4*>(st.rays[0])[2 * (size_t)pid] = make_float4(r.ox, r.oy, r.oz, r.tmin);
+        reinterpret_cast<float4*>(st.rays[0])[2 * (size_t)pid + 1] = make_float4(r.dx, r.dy, r.dz, r.tmax);
+        st.pids[0][pid] = pid;
+        st.transport[pid] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        st.radiance[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) st.ext_counts[0] = total;
+}
+
+struct Bsdf {
+    bool is_delta;
+    float pdf;
+    V3 bsdf, wo;
+};
+
+// material.rs:74-82
+__device__ inline Bsdf sample_specular(V3 wi, V3 n, V3 color, float probability) {
+    const V3 mi = -wi;
+    const V3 wo = normalize(mi - 2.0f * dot(mi, n) * n);  // reflect(-wi, n), material.rs:17-19
+    return Bsdf{true, probability, color, wo};
+}
+
+// material.rs:167-191 with its helpers (:34-38, :84-136) and AlbedoSource::get (albedo.rs:10-28)
+__device__ inline Bsdf material_sample(const DevMaterial& m, V3 wi, V3 n, float uvx, float uvy, uint64_t key,
+                                       uint32_t dim) {
+    const float cos_theta0 = fmaxf(dot(wi, n), 0.0f);
+    const float b = 1.0f - cos_theta0;
+    const float b2 = b * b;
+    const float t5 = b * (b2 * b2);  // powi(5)
+    const V3 r0 = v3(m.f0[0], m.f0[1], m.f0[2]);
+    const V3 f = r0 + (1.0f - r0) * t5;
+    V3 diffuse;
+    if (m.texture < 0) {
+        diffuse = v3(m.albedo[0], m.albedo[1], m.albedo[2]);
+    } else {
+        float wx = uvx - floorf(uvx), wy = uvy - floorf(uvy);
+        wx = wx == 1.0f ? 0.0f : wx;
+        wy = wy == 1.0f ? 0.0f : wy;
+        const uint32_t px = (uint32_t)floorf((float)m.tex_w * wx), py = (uint32_t)floorf((float)m.tex_h * wy);
+        const float* t = m.tex_rgb + ((size_t)py * m.tex_w + px) * 3;
+        diffuse = v3(t[0], t[1], t[2]);
+    }
+    const V3 td = (1.0f - f) * diffuse;
+    const float specular_strength = luminance(f);
+    const float diffuse_strength = luminance(td) * (1.0f - m.transmission);
+    const float refraction_strength = luminance(td) * m.transmission;
+    const float total = specular_strength + diffuse_strength + refraction_strength;
+    if (total <= 0.0f) return Bsdf{true, 0.0f, v3(0, 0, 0), n};
+    const float p_specular = specular_strength / total;
+    const float p_diffuse = diffuse_strength / total;
+    const float p_refraction = refraction_strength / total;
+    const float r = ptx_u01(key, dim);
+    if (p_specular > 0.0f && r < p_specular) return sample_specular(wi, n, f, p_specular);
+    if (r < p_specular + p_refraction) {
+        // sample_refraction(surface, ior, f, td, p_refraction), material.rs:84-112
+        const bool entering = dot(wi, n) < 0.0f;
+        const float n1 = entering ? 1.0f : m.ior, n2 = entering ? m.ior : 1.0f;
+        const float eta = n1 / n2;
+        const V3 normal = entering ? n : -n;
+        const V3 incoming = -wi;
+        const float ci = dot(incoming, normal);
+        const float s2 = eta * eta * (1.0f - ci * ci);
+        if (s2 >= 1.0f) return sample_specular(wi, n, f, p_refraction);
+        const float ct = sqrtf(1.0f - s2);
+        const V3 wo = normalize(eta * incoming + (eta * ci - ct) * normal);
+        const float eta_scale = (n2 * n2) / (n1 * n1);
+        return Bsdf{true, p_refraction, td * eta_scale, wo};
+    }
+    if (p_diffuse > 0.0f) {
+        // sample_diffuse, material.rs:114-136; perpendicular :21-32; cosine hemisphere sampling.rs:27-48
+        const float ax = fabsf(n.x), ay = fabsf(n.y), az = fabsf(n.z);
+        V3 perp;
+        if (ax < ay && ax < az) perp = v3(0.0f, -n.z, n.y);
+        else if (ay < az) perp = v3(-n.z, 0.0f, n.x);
+        else perp = v3(-n.y, n.x, 0.0f);
+        const V3 tangent = normalize(perp);
+        const V3 bitangent = cross(n, tangent);
+        const float x = ptx_sym_closed(key, dim + 1), y = ptx_sym_closed(key, dim + 2);
+        float hx = 0.0f, hy = 0.0f;
+        if (!(x == 0.0f && y == 0.0f)) {
+            float rr, theta;
+            if (x >= -y && x > y) {
+                rr = x;
+                theta = y / x;
+            } else if (x >= -y) {
+                rr = y;
+                theta = 2.0f - x / y;
+            } else if (x <= y) {
+                rr = -x;
+                theta = 4.0f + y / x;
+            } else {
+                rr = -y;
+                theta = 6.0f - x / y;
+            }
+            float sn, cs;
+            ptx_sincos(theta * 0.785398163397448309616f, &sn, &cs);
+            hx = rr * sn;
+            hy = rr * cs;
+        }
+        const float hz = sqrtf(fmaxf(0.0f, 1.0f - hx * hx - hy * hy));
+        const V3 wo = normalize(hx * tangent + hy * bitangent + hz * n);
+        const float cos_theta = fmaxf(dot(wo, n), 0.0f);
+        const float inv_pi = 0.318309886183790671538f;
+        return Bsdf{false, p_diffuse * cos_theta * inv_pi, td * inv_pi, wo};
+    }
+    return Bsdf{true, 0.0f, v3(0, 0, 0), n};
+}
+
+// One bounce of trace_ray (pathtracer.rs:33-108) for every entry of the current extend queue.
+__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, uint32_t bounce /* 1-based */) {
+    __shared__ uint32_t lds[WAVES + 1];
+    const uint32_t q = (bounce - 1u) & 1u;
+    const ptx_ray* __restrict__ rays_in = st.rays[q];
+    const uint32_t* __restrict__ pid_in = st.pids[q];
+    ptx_ray* __restrict__ rays_out = st.rays[q ^ 1u];
+    uint32_t* __restrict__ pid_out = st.pids[q ^ 1u];
+    const uint32_t count = st.ext_counts[bounce - 1u];
+    const uint32_t n_lights = sc.n_lights;
+    const uint32_t base = ptx_dim_base(bounce, n_lights);
+
+    for (uint32_t start = blockIdx.x * BLOCK; start < count; start += gridDim.x * BLOCK) {
+        const uint32_t i = start + threadIdx.x;
+        const bool active = i < count;
+        bool emit_next = false, emit_shadow = false;
+        uint32_t pid = 0;
+        V3 next_o = v3(0, 0, 0), next_d = v3(0, 0, 0), point_above = v3(0, 0, 0), T_old = v3(0, 0, 0);
+        V3 sh_dir[PTX_MAX_LIGHTS], sh_c[PTX_MAX_LIGHTS];
+        if (active) {
+            pid = pid_in[i];
+            const float4 ra = reinterpret_cast<const float4*>(rays_in)[2 * (size_t)i];
+            const float4 rb = reinterpret_cast<const float4*>(rays_in)[2 * (size_t)i + 1];
+            const uint4 hraw = reinterpret_cast<const uint4*>(st.hits)[i];
+            const float4 Traw = st.transport[pid];
+            const V3 T = v3(Traw.x, Traw.y, Traw.z);
+            if (hraw.x == PTX_MISS) {
+                // return accumulated_radiance + accumulated_transport * environment (pathtracer.rs:44-46)
+                float4 R = st.radiance[pid];
+                R.x = R.x + T.x * sc.env[0];
+                R.y = R.y + T.y * sc.env[1];
+                R.z = R.z + T.z * sc.env[2];
+                st.radiance[pid] = R;
+            } else {
+                const float ht = u2f(hraw.y), hu = u2f(hraw.z), hv = u2f(hraw.w);
+                const V3 ro = v3(ra.x, ra.y, ra.z), rd = v3(rb.x, rb.y, rb.z);
+                const float4 p0 = sc.props[4 * (size_t)hraw.x], p1 = sc.props[4 * (size_t)hraw.x + 1];
+                const float4 p2 = sc.props[4 * (size_t)hraw.x + 2], p3 = sc.props[4 * (size_t)hraw.x + 3];
+                const V3 n0 = v3(p0.x, p0.y, p0.z), n1 = v3(p0.w, p1.x, p1.y), n2 = v3(p1.z, p1.w, p2.x);
+                const float w = 1.0f - (hu + hv);
+                // TriangleNormals::lerp / TriangleTexcoords::lerp (geometry/src/triangle.rs:144-160)
+                const V3 n = normalize(w * n0 + hu * n1 + hv * n2);
+                const float uvx = w * p2.y + hu * p2.w + hv * p3.y;
+                const float uvy = w * p2.z + hu * p3.x + hv * p3.z;
+                const DevMaterial& mat = sc.materials[f2u(p3.w)];
+                const V3 wi = -rd;
+                const V3 offset = 0.00001f * n;
+                const V3 point = ro + ht * rd;
+                point_above = point + offset;
+                const V3 point_below = point - offset;
+                const uint32_t pixel = pid % st.n_pixels, s = pid / st.n_pixels;
+                const uint64_t key = ptx_path_key(st.seed, pixel, st.first_sample + s);
+                const Bsdf smp = material_sample(mat, wi, n, uvx, uvy, key, base);
+
+                if (!smp.is_delta && n_lights > 0) {
+                    emit_shadow = true;
+                    T_old = T;
+                    for (uint32_t l = 0; l < n_lights; ++l) {
+                        // Light::sample_shadow_ray (light.rs:34-37,69-76), uniform_sample_unit_sphere (sampling.rs:9-17)
+                        const ptx_light& L = sc.lights[l];
+                        const float z = ptx_sym_open(key, base + 3u + 2u * l);
+                        const float a = ptx_angle(key, base + 4u + 2u * l);
+                        const float r = sqrtf(1.0f - z * z);
+                        float sn, cs;
+                        ptx_sincos(a, &sn, &cs);
+                        const V3 center = v3(L.center[0], L.center[1], L.center[2]);
+                        const V3 target = center + v3(r * cs, r * sn, z) * L.radius;
+                        const V3 dir = target - point_above;
+                        // emitted(&point) (light.rs:17-19), |wo . n| with wo = normalize(shadow dir) (pathtracer.rs:79-81)
+                        const V3 cp = center - point;
+                        const V3 emitted = v3(L.intensity[0], L.intensity[1], L.intensity[2]) / dot(cp, cp);
+                        const V3 wo = normalize(dir);
+                        sh_dir[l] = dir;
+                        sh_c[l] = smp.bsdf * emitted * fabsf(dot(wo, n));
+                    }
+                }
+                if (smp.pdf != 0.0f) {
+                    const float cosine = dot(smp.wo, n);
+                    V3 Tn;
+                    if (smp.is_delta) Tn = T * smp.bsdf;
+                    else Tn = T * (smp.bsdf * (fabsf(cosine) / smp.pdf));
+                    st.transport[pid] = make_float4(Tn.x, Tn.y, Tn.z, 0.0f);
+                    if (!(dot(Tn, Tn) <= 1.0e-4f) && bounce < sc.max_bounces) {
+                        emit_next = true;
+                        next_o = cosine >= 0.0f ? point_above : point_below;
+                        next_d = smp.wo;
+                    }
+                }
+            }
+        }
+        const uint32_t slot_n = block_slot(emit_next, &st.ext_counts[bounce], lds);
+        if (emit_next) {
+            reinterpret_cast<float4*>(rays_out)[2 * (size_t)slot_n] = make_float4(next_o.x, next_o.y, next_o.z, 0.0f);
+            reinterpret_cast<float4*>(rays_out)[2 * (size_t)slot_n + 1] =
+                make_float4(next_d.x, next_d.y, next_d.z, 3.402823466e+38f);
+            pid_out[slot_n] = pid;
+        }
+        if (n_lights > 0) {
+            const uint32_t slot_s = block_slot(emit_shadow, &st.sh_counts[bounce - 1u], lds);
+            if (emit_shadow) {
+                st.sh_origin[slot_s] = make_float4(point_above.x, point_above.y, point_above.z, u2f(pid));
+                st.sh_T[slot_s] = make_float4(T_old.x, T_old.y, T_old.z, 0.0f);
+                for (uint32_t l = 0; l < n_lights; ++l) {
+                    st.sh_dir[(size_t)slot_s * n_lights + l] = make_float4(sh_dir[l].x, sh_dir[l].y, sh_dir[l].z, 0.0f);
+                    st.sh_contrib[(size_t)slot_s * n_lights + l] = make_float4(sh_c[l].x, sh_c[l].y, sh_c[l].z, 0.0f);
+                }
+            }
+        }
+    }
+}
+
+// Next-event estimation resolve: accumulated_radiance += accumulated_transport * sum over lights of the
+// unoccluded contributions, in MTL light order (pathtracer.rs:68-86).  One path per lane.
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_shadow(DevScene sc, RenderState st, uint32_t bounce) {
+    const uint32_t count = st.sh_counts[bounce - 1u];
+    const uint32_t n_lights = sc.n_lights;
+    WorkCount wc{0, 0};
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
+        const float4 o = st.sh_origin[i];
+        const float4 T = st.sh_T[i];
+        const uint32_t pid = f2u(o.w);
+        V3 incoming = v3(0.0f, 0.0f, 0.0f);
+        for (uint32_t l = 0; l < n_lights; ++l) {
+            const float4 d = st.sh_dir[(size_t)i * n_lights + l];
+            ptx_hit h;
+            const bool occ = kd_traverse<true, COUNT>(sc.nodes, sc.leaf_idx, sc.tris, o.x, o.y, o.z, d.x, d.y, d.z,
+                                                      0.0f, 1.0f, h, wc);
+            V3 c = v3(0.0f, 0.0f, 0.0f);
+            if (!occ) {
+                const float4 cc = st.sh_contrib[(size_t)i * n_lights + l];
+                c = v3(cc.x, cc.y, cc.z);
+            }
+            incoming = incoming + c;
+        }
+        float4 R = st.radiance[pid];
+        R.x = R.x + T.x * incoming.x;
+        R.y = R.y + T.y * incoming.y;
+        R.z = R.z + T.z * incoming.z;
+        st.radiance[pid] = R;
+    }
+    if (COUNT) {
+        wave_add(&st.totals[4], wc.inner);
+        wave_add(&st.totals[5], wc.tris);
+    }
+}
+
+// `*value += render_pixel(..)` (pathtracer.rs:138-140), samples added in index order.
+__global__ __launch_bounds__(BLOCK) void k_accumulate(RenderState st, float* __restrict__ accum) {
+    for (uint32_t pixel = blockIdx.x * BLOCK + threadIdx.x; pixel < st.n_pixels; pixel += gridDim.x * BLOCK) {
+        float r = accum[3 * (size_t)pixel], g = accum[3 * (size_t)pixel + 1], b = accum[3 * (size_t)pixel + 2];
+        for (uint32_t s = 0; s < st.n_samples; ++s) {
+            const float4 v = st.radiance[(size_t)s * st.n_pixels + pixel];
+            r += v.x;
+            g += v.y;
+            b += v.z;
+        }
+        accum[3 * (size_t)pixel] = r;
+        accum[3 * (size_t)pixel + 1] = g;
+        accum[3 * (size_t)pixel + 2] = b;
+    }
+}
+
+__global__ void k_tally(RenderState st, uint32_t max_bounces, uint32_t n_lights) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        unsigned long long e = 0, s = 0;
+        for (uint32_t b = 0; b < max_bounces; ++b) {
+            e += st.ext_counts[b];
+            s += (unsigned long long)st.sh_counts[b] * n_lights;
+        }
+        st.totals[0] += e;
+        st.totals[1] += s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t ensure(size_t count) {
+        if (count <= n) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    hipError_t upload(const T* src, size_t count) {
+        hipError_t e = ensure(count ? count : 1);
+        if (e != hipSuccess || !count) return e;
+        return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+int hip_fail(hipError_t e, const char* where) {
+    int code = e == hipErrorOutOfMemory ? PTX_E_OOM : PTX_E_HIP;
+    return fail(code, std::string(where) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                        \
+    do {                                                     \
+        hipError_t e__ = (expr);                             \
+        if (e__ != hipSuccess) return hip_fail(e__, #expr);  \
+    } while (0)
+
+enum KernelClass { KC_GENERATE = 0, KC_EXTEND, KC_SHADE, KC_SHADOW, KC_OTHER, KC_COUNT };
+
+}  // namespace
+
+struct ptx_scene {
+    int device = 0;
+    uint32_t flags = 0;
+    uint32_t n_triangles = 0, n_nodes = 0;
+    bool shading = false;
+    DevBuf<ptx_kdnode> nodes;
+    DevBuf<uint32_t> leaf_idx;
+    DevBuf<TriRec> tris;
+    DevBuf<float4> props;
+    DevBuf<DevMaterial> materials;
+    std::vector<std::unique_ptr<DevBuf<float>>> textures;
+    DevScene dev{};
+    int grid = 2048;
+
+    // render state (allocated on first render, grown on demand)
+    uint32_t batch_samples = 0;  // 0 = choose from the image size
+    size_t cap_paths = 0;
+    uint32_t cap_lights = 0, cap_bounces = 0;
+    DevBuf<ptx_ray> rays[2];
+    DevBuf<uint32_t> pids[2];
+    DevBuf<ptx_hit> hits;
+    DevBuf<float4> transport, radiance, sh_origin, sh_T, sh_dir, sh_contrib;
+    DevBuf<uint32_t> counts;
+    DevBuf<unsigned long long> totals;
+    uint64_t samples_done = 0;
+    uint64_t batch_extend_rays = 0, batch_shadow_rays = 0;  // rays of the *_batch entry points
+
+    // kernel timing (PTX_FLAG_TIME_KERNELS)
+    struct Stamp {
+        hipEvent_t a, b;
+        int cls;
+    };
+    std::vector<Stamp> stamps;
+    std::vector<hipEvent_t> free_events;
+    double class_ms[KC_COUNT] = {0, 0, 0, 0, 0};
+    double total_ms = 0;
+
+    // staging for ptx_intersect_batch
+    DevBuf<ptx_ray> stage_rays;
+    DevBuf<ptx_hit> stage_hits;
+    DevBuf<float> stage_accum;
+
+    ~ptx_scene() {
+        for (auto& s : stamps) {
+            (void)hipEventDestroy(s.a);
+            (void)hipEventDestroy(s.b);
+        }
+        for (auto e : free_events) (void)hipEventDestroy(e);
+    }
+};
+
+namespace {
+
+hipEvent_t take_event(ptx_scene* sc) {
+    if (!sc->free_events.empty()) {
+        hipEvent_t e = sc->free_events.back();
+        sc->free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct Timed {  // RAII bracket of one launch with two events when timing is on
+    ptx_scene* sc;
+    hipStream_t stream;
+    ptx_scene::Stamp st{};
+    bool on;
+    Timed(ptx_scene* s, hipStream_t str, int cls) : sc(s), stream(str), on((s->flags & PTX_FLAG_TIME_KERNELS) != 0) {
+        if (on) {
+            st.a = take_event(sc);
+            st.b = take_event(sc);
+            st.cls = cls;
+            (void)hipEventRecord(st.a, stream);
+        }
+    }
+    ~Timed() {
+        if (on) {
+            (void)hipEventRecord(st.b, stream);
+            sc->stamps.push_back(st);
+        }
+    }
+};
+
+void resolve_stamps(ptx_scene* sc) {
+    for (auto& s : sc->stamps) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess)
+            sc->class_ms[s.cls] += ms;
+        sc->free_events.push_back(s.a);
+        sc->free_events.push_back(s.b);
+    }
+    sc->stamps.clear();
+}
+
+int ensure_render_state(ptx_scene* sc, size_t paths) {
+    const uint32_t L = sc->dev.n_lights ? sc->dev.n_lights : 1u;
+    const uint32_t B = sc->dev.max_bounces;
+    if (paths <= sc->cap_paths && L <= sc->cap_lights && B <= sc->cap_bounces) return PTX_OK;
+    for (int q = 0; q < 2; ++q) {
+        HIP_TRY(sc->rays[q].ensure(paths));
+        HIP_TRY(sc->pids[q].ensure(paths));
+    }
+    HIP_TRY(sc->hits.ensure(paths));
+    HIP_TRY(sc->transport.ensure(paths));
+    HIP_TRY(sc->radiance.ensure(paths));
+    HIP_TRY(sc->sh_origin.ensure(paths));
+    HIP_TRY(sc->sh_T.ensure(paths));
+    HIP_TRY(sc->sh_dir.ensure(paths * L));
+    HIP_TRY(sc->sh_contrib.ensure(paths * L));
+    HIP_TRY(sc->counts.ensure(2 * (size_t)B + 2));
+    if (!sc->totals.p) {
+        HIP_TRY(sc->totals.ensure(8));
+        HIP_TRY(hipMemset(sc->totals.p, 0, 8 * sizeof(unsigned long long)));
+    }
+    sc->cap_paths = paths;
+    sc->cap_lights = L;
+    sc->cap_bounces = B;
+    return PTX_OK;
+}
+
+int check_scene(ptx_scene* sc, const char* who) {
+    if (!sc) return fail(PTX_E_ARG, std::string(who) + ": null scene");
+    hipError_t e = hipSetDevice(sc->device);
+    if (e != hipSuccess) return hip_fail(e, who);
+    return PTX_OK;
+}
+
+template <bool ANY>
+int launch_traverse(ptx_scene* sc, const ptx_ray* d_rays, const uint32_t* d_count, uint32_t n, ptx_hit* d_hits,
+                    uint8_t* d_occ, unsigned long long* work, hipStream_t stream) {
+    const bool count = (sc->flags & PTX_FLAG_COUNT_WORK) != 0 && work;
+    int grid = sc->grid;
+    if (!d_count) {
+        int need = (int)((n + BLOCK - 1) / BLOCK);
+        if (need < grid) grid = need > 0 ? need : 1;
+    }
+    if (count)
+        k_traverse<ANY, true><<<grid, BLOCK, 0, stream>>>(sc->dev.nodes, sc->dev.leaf_idx, sc->dev.tris, d_rays, d_count,
+                                                          n, d_hits, d_occ, work);
+    else
+        k_traverse<ANY, false><<<grid, BLOCK, 0, stream>>>(sc->dev.nodes, sc->dev.leaf_idx, sc->dev.tris, d_rays,
+                                                           d_count, n, d_hits, d_occ, nullptr);
+    HIP_TRY(hipGetLastError());
+    return PTX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptx_scene_create(const ptx_scene_desc* d, uint32_t flags, ptx_scene** out) {
+    if (!d || !out) return fail(PTX_E_ARG, "ptx_scene_create: null argument");
+    if (!d->nodes || d->n_nodes == 0) return fail(PTX_E_ARG, "ptx_scene_create: tree has no nodes");
+    if (d->n_triangles && !d->triangles) return fail(PTX_E_ARG, "ptx_scene_create: triangles missing");
+    if (d->n_leaf_indices && !d->leaf_indices) return fail(PTX_E_ARG, "ptx_scene_create: leaf index list missing");
+    if (d->n_lights > PTX_MAX_LIGHTS) return fail(PTX_E_LIMIT, "ptx_scene_create: more than PTX_MAX_LIGHTS lights");
+    if (d->n_lights && !d->lights) return fail(PTX_E_ARG, "ptx_scene_create: lights missing");
+    if (d->max_bounces > 255) return fail(PTX_E_LIMIT, "ptx_scene_create: max_bounces is a u8 in the reference (<= 255)");
+    // the kernels index with what the tree says: prove every index in range before anything is launched
+    std::string why = validate_flat_tree(d->nodes, d->n_nodes, d->leaf_indices, d->n_leaf_indices, d->n_triangles);
+    if (!why.empty()) return fail(PTX_E_ARG, "ptx_scene_create: invalid flattened tree: " + why);
+    const bool shading = d->normals && d->texcoords && d->material_ids && d->materials && d->n_materials;
+    if (shading) {
+        for (uint32_t i = 0; i < d->n_triangles; ++i)
+            if (d->material_ids[i] >= d->n_materials) return fail(PTX_E_ARG, "ptx_scene_create: material id out of range");
+        for (uint32_t i = 0; i < d->n_materials; ++i) {
+            int32_t t = d->materials[i].texture;
+            if (t >= (int32_t)d->n_textures) return fail(PTX_E_ARG, "ptx_scene_create: texture index out of range");
+            if (t >= 0 && (!d->textures || !d->textures[t].rgb || !d->textures[t].width || !d->textures[t].height))
+                return fail(PTX_E_ARG, "ptx_scene_create: empty texture");
+        }
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return fail(PTX_E_HIP, "ptx_scene_create: no HIP device available");
+    auto sc = std::make_unique<ptx_scene>();
+    HIP_TRY(hipGetDevice(&sc->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, sc->device));
+    sc->grid = prop.multiProcessorCount * 8;
+    sc->flags = flags;
+    sc->n_triangles = d->n_triangles;
+    sc->n_nodes = d->n_nodes;
+    sc->shading = shading;
+
+    std::vector<TriRec> recs;
+    pack_triangles(d->triangles, d->n_triangles, recs);
+    HIP_TRY(sc->nodes.upload(d->nodes, d->n_nodes));
+    HIP_TRY(sc->leaf_idx.upload(d->leaf_indices, d->n_leaf_indices));
+    HIP_TRY(sc->tris.upload(recs.data(), recs.size()));
+    sc->dev.nodes = sc->nodes.p;
+    sc->dev.leaf_idx = sc->leaf_idx.p;
+    sc->dev.tris = sc->tris.p;
+    if (shading) {
+        std::vector<float4> props(4 * (size_t)d->n_triangles);
+        for (uint32_t i = 0; i < d->n_triangles; ++i) {
+            float f[16];
+            memcpy(f, d->normals + 9 * (size_t)i, 9 * sizeof(float));
+            memcpy(f + 9, d->texcoords + 6 * (size_t)i, 6 * sizeof(float));
+            memcpy(f + 15, &d->material_ids[i], 4);
+            memcpy(&props[4 * (size_t)i], f, sizeof f);
+        }
+        HIP_TRY(sc->props.upload(props.data(), props.size()));
+        std::vector<DevMaterial> mats(d->n_materials);
+        for (uint32_t t = 0; t < d->n_textures; ++t) {
+            auto buf = std::make_unique<DevBuf<float>>();
+            HIP_TRY(buf->upload(d->textures[t].rgb, (size_t)d->textures[t].width * d->textures[t].height * 3));
+            sc->textures.push_back(std::move(buf));
+        }
+        for (uint32_t i = 0; i < d->n_materials; ++i) {
+            const ptx_material& m = d->materials[i];
+            DevMaterial& o = mats[i];
+            memcpy(o.albedo, m.albedo, sizeof o.albedo);
+            memcpy(o.f0, m.schlick_f0, sizeof o.f0);
+            o.texture = m.texture;
+            o.transmission = m.transmission;
+            o.ior = m.ior;
+            o.tex_w = o.tex_h = 0;
+            o.tex_rgb = nullptr;
+            if (m.texture >= 0) {
+                o.tex_w = d->textures[m.texture].width;
+                o.tex_h = d->textures[m.texture].height;
+                o.tex_rgb = sc->textures[m.texture]->p;
+            }
+        }
+        HIP_TRY(sc->materials.upload(mats.data(), mats.size()));
+        sc->dev.props = sc->props.p;
+        sc->dev.materials = sc->materials.p;
+    }
+    sc->dev.n_lights = d->n_lights;
+    for (uint32_t l = 0; l < d->n_lights; ++l) sc->dev.lights[l] = d->lights[l];
+    memcpy(sc->dev.env, d->environment, sizeof sc->dev.env);
+    sc->dev.max_bounces = d->max_bounces;
+    HIP_TRY(sc->totals.ensure(8));
+    HIP_TRY(hipMemset(sc->totals.p, 0, 8 * sizeof(unsigned long long)));
+    *out = sc.release();
+    return PTX_OK;
+}
+
+void ptx_scene_destroy(ptx_scene* scene) {
+    if (!scene) return;
+    (void)hipSetDevice(scene->device);
+    (void)hipDeviceSynchronize();
+    delete scene;
+}
+
+int ptx_intersect_batch_device(ptx_scene* sc, const ptx_ray* d_rays, size_t n, ptx_hit* d_hits, void* stream) {
+    int rc = check_scene(sc, "ptx_intersect_batch_device");
+    if (rc) return rc;
+    if (n == 0) return PTX_OK;
+    if (!d_rays || !d_hits) return fail(PTX_E_ARG, "ptx_intersect_batch_device: null buffer");
+    if (n > 0xFFFFFFFFull) return fail(PTX_E_LIMIT, "ptx_intersect_batch_device: more than 2^32-1 rays in one call");
+    Timed tm(sc, (hipStream_t)stream, KC_EXTEND);
+    sc->batch_extend_rays += n;
+    return launch_traverse<false>(sc, d_rays, nullptr, (uint32_t)n, d_hits, nullptr, sc->totals.p + 2, (hipStream_t)stream);
+}
+
+int ptx_occluded_batch_device(ptx_scene* sc, const ptx_ray* d_rays, size_t n, uint8_t* d_out, void* stream) {
+    int rc = check_scene(sc, "ptx_occluded_batch_device");
+    if (rc) return rc;
+    if (n == 0) return PTX_OK;
+    if (!d_rays || !d_out) return fail(PTX_E_ARG, "ptx_occluded_batch_device: null buffer");
+    if (n > 0xFFFFFFFFull) return fail(PTX_E_LIMIT, "ptx_occluded_batch_device: more than 2^32-1 rays in one call");
+    Timed tm(sc, (hipStream_t)stream, KC_SHADOW);
+    sc->batch_shadow_rays += n;
+    return launch_traverse<true>(sc, d_rays, nullptr, (uint32_t)n, nullptr, d_out, sc->totals.p + 4, (hipStream_t)stream);
+}
+
+int ptx_intersect_batch(ptx_scene* sc, const ptx_ray* rays, size_t n, ptx_hit* hits) {
+    int rc = check_scene(sc, "ptx_intersect_batch");
+    if (rc) return rc;
+    if (n == 0) return PTX_OK;
+    if (!rays || !hits) return fail(PTX_E_ARG, "ptx_intersect_batch: null buffer");
+    const size_t chunk = (size_t)1 << 24;
+    HIP_TRY(sc->stage_rays.ensure(n < chunk ? n : chunk));
+    HIP_TRY(sc->stage_hits.ensure(n < chunk ? n : chunk));
+    for (size_t at = 0; at < n; at += chunk) {
+        size_t m = n - at < chunk ? n - at : chunk;
+        HIP_TRY(hipMemcpy(sc->stage_rays.p, rays + at, m * sizeof(ptx_ray), hipMemcpyHostToDevice));
+        rc = ptx_intersect_batch_device(sc, sc->stage_rays.p, m, sc->stage_hits.p, nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpy(hits + at, sc->stage_hits.p, m * sizeof(ptx_hit), hipMemcpyDeviceToHost));
+    }
+    return PTX_OK;
+}
+
+int ptx_set_batch_samples(ptx_scene* sc, uint32_t samples_per_batch) {
+    if (!sc) return fail(PTX_E_ARG, "ptx_set_batch_samples: null scene");
+    sc->batch_samples = samples_per_batch;
+    return PTX_OK;
+}
+
+static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uint32_t first_sample,
+                       uint32_t sample_count, float* d_accum, hipStream_t stream, ptx_progress_cb progress,
+                       void* user) {
+    if (!cam || !d_accum) return fail(PTX_E_ARG, "ptx_render: null argument");
+    if (!sc->shading) return fail(PTX_E_ARG, "ptx_render: scene was created without shading data");
+    if (cam->width == 0 || cam->height == 0) return fail(PTX_E_ARG, "ptx_render: empty image");
+    const uint64_t n_pixels64 = (uint64_t)cam->width * cam->height;
+    if (n_pixels64 > (1ull << 27)) return fail(PTX_E_LIMIT, "ptx_render: image larger than 2^27 pixels");
+    if ((uint64_t)first_sample + sample_count > 0xFFFFFFFFull) return fail(PTX_E_LIMIT, "ptx_render: sample index overflow");
+    const uint32_t n_pixels = (uint32_t)n_pixels64;
+    uint32_t S = sc->batch_samples;
+    if (S == 0) {
+        S = (uint32_t)((6u << 20) / n_pixels);
+        if (S < 1) S = 1;
+        if (S > 64) S = 64;
+    }
+    while ((uint64_t)S * n_pixels > (1ull << 28)) S = (S + 1) / 2;  // path ids are 32-bit; keep slots < 2^28
+    if (S > sample_count && sample_count > 0) S = sample_count;
+    int rc = ensure_render_state(sc, (size_t)S * n_pixels);
+    if (rc) return rc;
+
+    const uint32_t B = sc->dev.max_bounces, L = sc->dev.n_lights;
+    RenderState st{};
+    st.rays[0] = sc->rays[0].p;
+    st.rays[1] = sc->rays[1].p;
+    st.pids[0] = sc->pids[0].p;
+    st.pids[1] = sc->pids[1].p;
+    st.hits = sc->hits.p;
+    st.transport = sc->transport.p;
+    st.radiance = sc->radiance.p;
+    st.sh_origin = sc->sh_origin.p;
+    st.sh_T = sc->sh_T.p;
+    st.sh_dir = sc->sh_dir.p;
+    st.sh_contrib = sc->sh_contrib.p;
+    st.ext_counts = sc->counts.p;
+    st.sh_counts = sc->counts.p + (B + 1);
+    st.totals = sc->totals.p;
+    st.cam = *cam;
+    st.seed = seed;
+    st.n_pixels = n_pixels;
+    const bool count = (sc->flags & PTX_FLAG_COUNT_WORK) != 0;
+    const int grid = sc->grid;
+    auto t0 = std::chrono::steady_clock::now();
+
+    for (uint32_t done = 0; done < sample_count; done += S) {
+        const uint32_t ns = sample_count - done < S ? sample_count - done : S;
+        st.n_samples = ns;
+        st.first_sample = first_sample + done;
+        HIP_TRY(hipMemsetAsync(sc->counts.p, 0, (2 * (size_t)B + 2) * sizeof(uint32_t), stream));
+        {
+            Timed tm(sc, stream, KC_GENERATE);
+            k_generate<<<grid, BLOCK, 0, stream>>>(st);
+        }
+        for (uint32_t b = 1; b <= B; ++b) {
+            {
+                Timed tm(sc, stream, KC_EXTEND);
+                rc = launch_traverse<false>(sc, st.rays[(b - 1) & 1], st.ext_counts + (b - 1), 0, st.hits, nullptr,
+                                            sc->totals.p + 2, stream);
+                if (rc) return rc;
+            }
+            {
+                Timed tm(sc, stream, KC_SHADE);
+                k_shade<<<grid, BLOCK, 0, stream>>>(sc->dev, st, b);
+            }
+            if (L > 0) {
+                Timed tm(sc, stream, KC_SHADOW);
+                if (count) k_shadow<true><<<grid, BLOCK, 0, stream>>>(sc->dev, st, b);
+                else k_shadow<false><<<grid, BLOCK, 0, stream>>>(sc->dev, st, b);
+            }
+        }
+        {
+            Timed tm(sc, stream, KC_OTHER);
+            k_accumulate<<<grid, BLOCK, 0, stream>>>(st, d_accum);
+            k_tally<<<1, 64, 0, stream>>>(st, B, L);
+        }
+        HIP_TRY(hipGetLastError());
+        sc->samples_done += (uint64_t)ns * n_pixels;
+        if (progress) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            progress(done + ns, secs, user);
+        }
+    }
+    return PTX_OK;
+}
+
+int ptx_render_device(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uint32_t first_sample,
+                      uint32_t sample_count, float* d_accum, void* stream) {
+    int rc = check_scene(sc, "ptx_render_device");
+    if (rc) return rc;
+    return render_impl(sc, cam, seed, first_sample, sample_count, d_accum, (hipStream_t)stream, nullptr, nullptr);
+}
+
+int ptx_render(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uint32_t first_sample, uint32_t sample_count,
+               float* accum_host, ptx_progress_cb progress, void* user) {
+    int rc = check_scene(sc, "ptx_render");
+    if (rc) return rc;
+    if (!cam || !accum_host) return fail(PTX_E_ARG, "ptx_render: null argument");
+    const size_t n = (size_t)cam->width * cam->height * 3;
+    if (n == 0) return fail(PTX_E_ARG, "ptx_render: empty image");
+    HIP_TRY(sc->stage_accum.ensure(n));
+    HIP_TRY(hipMemcpy(sc->stage_accum.p, accum_host, n * sizeof(float), hipMemcpyHostToDevice));
+    auto t0 = std::chrono::steady_clock::now();
+    rc = render_impl(sc, cam, seed, first_sample, sample_count, sc->stage_accum.p, nullptr, progress, user);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    sc->total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    HIP_TRY(hipMemcpy(accum_host, sc->stage_accum.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return PTX_OK;
+}
+
+int ptx_stats(ptx_scene* sc, ptx_counters* out) {
+    int rc = check_scene(sc, "ptx_stats");
+    if (rc) return rc;
+    if (!out) return fail(PTX_E_ARG, "ptx_stats: null argument");
+    HIP_TRY(hipDeviceSynchronize());
+    resolve_stamps(sc);
+    unsigned long long t[8] = {0};
+    HIP_TRY(hipMemcpy(t, sc->totals.p, sizeof t, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof *out);
+    out->extend_rays = t[0] + sc->batch_extend_rays;
+    out->shadow_rays = t[1] + sc->batch_shadow_rays;
+    out->extend_inner_nodes = t[2];
+    out->extend_tri_tests = t[3];
+    out->shadow_inner_nodes = t[4];
+    out->shadow_tri_tests = t[5];
+    out->samples = sc->samples_done;
+    out->generate_ms = sc->class_ms[KC_GENERATE];
+    out->extend_ms = sc->class_ms[KC_EXTEND];
+    out->shade_ms = sc->class_ms[KC_SHADE];
+    out->shadow_ms = sc->class_ms[KC_SHADOW];
+    out->total_ms = sc->total_ms;
+    return PTX_OK;
+}
+
+int ptx_stats_reset(ptx_scene* sc) {
+    int rc = check_scene(sc, "ptx_stats_reset");
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    resolve_stamps(sc);
+    HIP_TRY(hipMemset(sc->totals.p, 0, 8 * sizeof(unsigned long long)));
+    for (double& v : sc->class_ms) v = 0;
+    sc->total_ms = 0;
+    sc->samples_done = 0;
+    sc->batch_extend_rays = sc->batch_shadow_rays = 0;
+    return PTX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,154 @@
+"""GPU parity (-m gpu): the HIP path through the C ABI against the CPU oracle on the same inputs.
+
+Bar: hit records (index, t, u, v) bit-exact; images bit-exact against the oracle's counter-sampler mode
+with one thread (same paths, same per-pixel summation order)."""
+import os
+
+import numpy as np
+import pytest
+
+import pathtracer_amd as pt
+import pyoracle as orc
+
+from test_oracle_kat import L, N, ray_between, reverse
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCENES = os.path.join(ROOT, "scenes")
+f32 = np.float32
+
+
+def synthetic_rays(lo, hi, n, seed):
+    """SURVEY §8d ray set B: origins uniform in the box enlarged by 10 %, directions uniform on the sphere,
+    plus segment rays between two points (t in [0,1]) and axis-parallel rays with +-0 components."""
+    rng = np.random.default_rng(seed)
+    c, h = (lo + hi) / 2, (hi - lo) / 2 * 1.1
+    o = (c + rng.uniform(-1, 1, (n, 3)) * h).astype(f32)
+    z = rng.uniform(-1, 1, n)
+    phi = rng.uniform(0, 2 * np.pi, n)
+    r = np.sqrt(1 - z * z)
+    d = np.stack([r * np.cos(phi), r * np.sin(phi), z], 1).astype(f32)
+    rays = orc.make_rays(o, d)
+    m = n // 4
+    p = (c + rng.uniform(-1, 1, (m, 3)) * h).astype(f32)
+    seg = orc.make_rays(o[:m], p - o[:m], 0.0, 1.0)
+    k = n // 8
+    ax = orc.make_rays(o[:k], d[:k])
+    axis = rng.integers(0, 3, k)
+    zero = np.where(rng.random(k) < 0.5, f32(0.0), f32(-0.0))
+    ax["d"][np.arange(k), axis] = zero
+    two = rng.random(k) < 0.3
+    ax["d"][np.arange(k)[two], (axis[two] + 1) % 3] = 0.0
+    return np.concatenate([rays, seg, ax])
+
+
+def assert_hits_equal(got, want):
+    same = got.tobytes() == want.tobytes()
+    if not same:
+        bad = np.where((got["index"] != want["index"]) | (got["t"].view(np.uint32) != want["t"].view(np.uint32))
+                       | (got["u"].view(np.uint32) != want["u"].view(np.uint32)) | (got["v"].view(np.uint32) != want["v"].view(np.uint32)))[0]
+        raise AssertionError("%d of %d hits differ, first %d: got %s want %s" % (len(bad), len(got), bad[0], got[bad[0]], want[bad[0]]))
+
+
+def test_reference_kdtree_vectors_on_gpu():  # kdtree/src/lib.rs:202-467
+    cases = []
+    tris = [[[0, 0, -1], [2, 0, -1], [2, 2, -1]], [[0, 0, 1], [2, 0, 1], [2, 2, 1]]]
+    ray = ray_between([1, 1, -2], [1, 1, 2])
+    cases.append((tris, N(0, 1.0, L(0, 1), L(0, 1)), [ray, reverse(ray)], 1.0, [(0, 0.25, 0.0, 0.5), (1, 0.25, 0.0, 0.5)]))
+    tris = [[[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[1, 0, 0], [2, 0, 0], [2, 1, 0]]]
+    cases.append((tris, N(0, 1.0, L(0), L(1)), [ray_between([0, 0, -1], [0, 0, 1]), ray_between([2, 0, -1], [2, 0, 1])], 1.0,
+                  [(0, 0.5, 0.0, 0.0), (1, 0.5, 1.0, 0.0)]))
+    z1 = [[[0, 0, 1], [1, 0, 1], [0, 1, 1]]]
+    ray = ray_between([0, 0, 0], [0, 0, 2])
+    for spec in (N(2, 1.0, L(0), L()), N(2, 1.0, L(), L(0)), N(2, 1.0, N(2, 1.0, L(0), L()), L()), N(2, 1.0, L(), N(2, 1.0, L(0), L()))):
+        cases.append((z1, spec, [ray, reverse(ray)], 1.0, [(0, 0.5, 0.0, 0.0)] * 2))
+    cases.append(([[[-1, -1, 1], [-1, -1, -1], [-1, 1, 1]]], N(0, -1.0, L(), L(0)),
+                  [(np.array([-0.5170438, -0.4394186, -0.045965273], f32), np.array([-0.8491798, -0.1408107, -0.5089852], f32))],
+                  pt.FMAX, [(0, 0.5687325, 0.66772085, 0.24024889)]))
+    for tris, spec, rays, tmax, expect in cases:
+        nodes, leaf = orc.flat_tree(spec)
+        dev = pt.DeviceScene.from_arrays(tris, nodes, leaf)
+        r = pt.make_rays([x[0] for x in rays], [x[1] for x in rays], 0.0, tmax)
+        hits = dev.intersect(r)
+        for h, e in zip(hits, expect):
+            assert (int(h["index"]), f32(h["t"]), f32(h["u"]), f32(h["v"])) == (e[0], f32(e[1]), f32(e[2]), f32(e[3]))
+        dev.close()
+    nodes, leaf = orc.flat_tree(L())
+    dev = pt.DeviceScene.from_arrays(np.zeros((0, 9), f32), nodes, leaf)  # empty tree (:203)
+    assert dev.intersect(pt.make_rays([[0, 0, 0]], [[1, 1, 1]], 0.0, 1.0))[0]["index"] == pt.MISS
+    assert len(dev.intersect(np.zeros(0, pt.RAY_DTYPE))) == 0  # empty batch
+    dev.close()
+
+
+@pytest.mark.parametrize("name,res", [("cornell", 96), ("cornell_teapot", 96), ("cornell_textured", 64), ("sr2", 64), ("cubesplosion", 64)])
+def test_extend_bit_exact_vs_oracle(name, res):
+    """Config 2: kdtree-tester-cli bounced ray set + synthetic rays; GPU == CPU pointer-tree traversal."""
+    path = os.path.join(SCENES, name + ".obj")
+    ref = orc.Scene(path)
+    bounced, fails = ref.bounce_rays(res, res, 10, seed=3, threads=8)
+    assert fails == 0  # kd-tree vs brute force inside the oracle (checked_intersection.rs tolerances)
+    tris = ref.export()["triangles"].reshape(-1, 3, 3)
+    rays = np.concatenate([bounced, synthetic_rays(tris.min((0, 1)), tris.max((0, 1)), 1 << 16, 0x5EED0001)])
+    tree = ref.tree()
+    want = tree.intersect(rays, threads=8)
+    scene = pt.LoadedScene(path)
+    dev = scene.upload()
+    got = dev.intersect(rays)
+    assert_hits_equal(got, want)
+    assert (got["index"] != pt.MISS).mean() > 0.2
+    dev.close()
+
+
+def test_occlusion_query_equals_is_some():
+    import torch
+
+    path = os.path.join(SCENES, "cornell_teapot.obj")
+    ref = orc.Scene(path)
+    bounced, _ = ref.bounce_rays(64, 64, 6, seed=9, threads=8)
+    want = ref.tree().intersect(bounced, threads=8)["index"] != orc.MISS
+    dev = pt.LoadedScene(path).upload()
+    d_rays = torch.from_numpy(bounced.view(np.uint8).copy()).cuda()
+    d_out = torch.zeros(len(bounced), dtype=torch.uint8, device="cuda")
+    dev.occluded_device(d_rays.data_ptr(), len(bounced), d_out.data_ptr())
+    torch.cuda.synchronize()
+    assert (d_out.cpu().numpy().astype(bool) == want).all()
+    dev.close()
+
+
+@pytest.mark.parametrize("name,w,h,spp,bounces", [("cornell", 48, 40, 3, 10), ("cornell_textured", 40, 40, 2, 10), ("cornell_teapot", 32, 32, 2, 6), ("sr2", 32, 18, 2, 4)])
+def test_render_bit_exact_vs_oracle_counter_mode(name, w, h, spp, bounces):
+    """Same counter-based sampler, one CPU thread: identical paths, identical per-pixel sum order."""
+    path = os.path.join(SCENES, name + ".obj")
+    ref = orc.Scene(path, max_bounces=bounces)
+    want, _ = ref.render(w, h, threads=1, iterations_per_thread=spp, mode=1, seed=77, first_sample=5)
+    scene = pt.LoadedScene(path, max_bounces=bounces)
+    dev = scene.upload()
+    got = dev.render(scene.pinhole(w, h), spp, seed=77, first_sample=5)
+    diff = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    assert np.isfinite(got).all()
+    assert got.tobytes() == want.tobytes(), "max abs diff %g at %s" % (diff.max(), np.unravel_index(diff.argmax(), diff.shape))
+    # batch split must not matter (counter-based sampler): one sample per batch gives the same image
+    dev.set_batch_samples(1)
+    again = dev.render(scene.pinhole(w, h), spp, seed=77, first_sample=5)
+    assert again.tobytes() == got.tobytes()
+    dev.close()
+
+
+def test_render_accumulates_into_buffer_and_counts_rays():
+    path = os.path.join(SCENES, "cornell.obj")
+    scene = pt.LoadedScene(path)
+    dev = scene.upload(flags=pt.FLAG_COUNT_WORK | pt.FLAG_TIME_KERNELS)
+    ph = scene.pinhole(32, 32)
+    a = dev.render(ph, 2, seed=1)
+    b = dev.render(ph, 2, seed=1, first_sample=2, accum=a.copy())
+    c = dev.render(ph, 4, seed=1)
+    assert b.tobytes() == c.tobytes()  # buffer is accumulated into, never cleared (image_buffer semantics)
+    ref = orc.Scene(path)
+    _, _, st = ref.render(32, 32, threads=1, iterations_per_thread=2, mode=1, seed=1, stats=True)
+    dev.stats_reset()
+    dev.render(ph, 2, seed=1)
+    s = dev.stats()
+    assert s["extend_rays"] == st["extend_rays"] and s["shadow_rays"] == st["shadow_rays"]
+    assert s["extend_inner_nodes"] == st["extend_inner_nodes"] and s["extend_tri_tests"] == st["extend_tri_tests"]
+    assert s["samples"] == 2 * 32 * 32 and s["extend_ms"] > 0
+    dev.close()
