@@ -105,6 +105,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise PtxError(-2, "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(or make -C pathtracer_amd/csrc); there is no CPU fallback" % LIB_PATH)
+        # PyTorch-ROCm ships its own libamdhip64.so.7; whichever HIP runtime is mapped first serves the
+        # whole process, and torch cannot find a GPU once the system runtime is in.  Torch (used for
+        # device tensors, streams and RCCL) therefore goes first when it is installed.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.ptx_last_error.restype = C.c_char_p
         L.ptx_version.restype = C.c_char_p
