@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py — render hot path throughput on MI355X (contract: see the task statement).
+
+A step = one pass of the wavefront path tracer (generate → [extend → shade → shadow] x max_bounces →
+accumulate) over one batch of `--spp-per-step` samples of every pixel of the workload; inputs (scene,
+accumulation buffer) are resident in HBM before the timed region.  Default workload = BASELINE.json
+configs[2]: cornell_teapot.obj, 1080x1080, 64 steps x 16 spp = 1024 spp per GPU, max_bounces 10.
+
+Multi-GPU: one process per GPU (torchrun), the scene replicated, every rank renders its own sample
+range (global sample index = rank * steps * spp + ...; counter-based sampler, so ranks never overlap),
+and the per-GPU accumulation buffers are summed on rank 0 with ONE RCCL reduce inside the timed region
+(the analogue of `buffers.reduce(Add::add)`, tracing/src/worker.rs:106-107).  Weak scaling.
+
+value = whole-job pixel samples per second.  The line also carries extend Mrays/s, the roofline of the
+dominant kernel (extend) from HIP-event timings taken inside the timed region, and a CPU baseline
+(the oracle — a C++ restatement of the reference, kind "port" — on a bounded sample, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scene", default="cornell_teapot")
+    ap.add_argument("--size", default="1080x1080")
+    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--max-bounces", type=int, default=10)
+    ap.add_argument("--batch-samples", type=int, default=0, help="samples in flight per launch batch (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--save", default="", help="write the tonemapped image (rank 0) to this PNG")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import pathtracer_amd as pt
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H = (int(x) for x in args.size.lower().split("x"))
+    obj = os.path.join(ROOT, "scenes", args.scene + ".obj")
+    t0 = time.perf_counter()
+    scene = pt.LoadedScene(obj, max_bounces=args.max_bounces)
+    load_s = time.perf_counter() - t0
+    flags = 0 if args.no_events else pt.FLAG_TIME_KERNELS
+    dev = scene.upload(flags=flags)
+    if args.batch_samples:
+        dev.set_batch_samples(args.batch_samples)
+    pinhole = scene.pinhole(W, H)
+    accum = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    spp = args.spp_per_step
+    base_sample = rank * (args.steps + args.warmup) * spp
+
+    def step(i):
+        dev.render_device(pinhole, spp, accum.data_ptr(), seed=0, first_sample=base_sample + i * spp, stream=stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:  # warm the communicator too
+        dist.reduce(torch.zeros(16, device="cuda"), dst=0)
+    fence()
+    accum.zero_()
+    dev.stats_reset()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    if world > 1:
+        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    st = dev.stats()
+    counts = torch.tensor([st["extend_rays"], st["shadow_rays"], st["samples"]], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    extend_rays, shadow_rays, samples = (float(x) for x in counts.tolist())
+
+    out = None
+    if rank == 0:
+        value = samples / elapsed
+        out = {
+            "metric": "samples/s (pixel samples, all kernels + RCCL reduce) with extend Mrays/s, %s %s" % (args.scene, args.size),
+            "value": value,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "scene files shipped in scenes/ (the reference's own resources); synthetic camera samples",
+            "config": {"workload": "%s.obj %s, %d spp per GPU (%d steps x %d spp), max_bounces %d" % (args.scene, args.size, args.steps * spp, args.steps, spp, args.max_bounces),
+                       "triangles": scene.n_triangles, "kd_nodes": int(scene.desc.n_nodes), "sharding": "samples per GPU, one RCCL reduce"},
+            "rays_per_s": (extend_rays + shadow_rays) / elapsed,
+            "extend_rays": extend_rays,
+            "shadow_rays": shadow_rays,
+            "scene_load_and_build_s": load_s,
+        }
+        if not args.no_events and st["extend_ms"] > 0:
+            # per-GPU kernel figures from rank 0's HIP events over the timed region
+            ext_ms, sh_ms = st["extend_ms"], st["shadow_ms"]
+            out["extend_mrays_per_s"] = st["extend_rays"] / ext_ms / 1e3
+            out["shadow_mrays_per_s"] = st["shadow_rays"] / sh_ms / 1e3 if sh_ms > 0 else None
+            out["kernel_ms"] = {"extend": ext_ms, "shadow": sh_ms, "shade": st["shade_ms"], "generate": st["generate_ms"]}
+            # algorithmic bytes per extend ray: 32 ray + 16 hit + 8 per inner node + 40 per triangle test,
+            # node/triangle counts measured on this workload by a counting pass outside the timed region
+            cdev = scene.upload(flags=pt.FLAG_COUNT_WORK)
+            tmp = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
+            cdev.render_device(pinhole, min(spp, 4), tmp.data_ptr(), seed=0, first_sample=base_sample, stream=stream)
+            torch.cuda.synchronize()
+            c = cdev.stats()
+            cdev.close()
+            nodes_per_ray = c["extend_inner_nodes"] / max(c["extend_rays"], 1)
+            tris_per_ray = c["extend_tri_tests"] / max(c["extend_rays"], 1)
+            b_ray = 48.0 + 8.0 * nodes_per_ray + 40.0 * tris_per_ray
+            launches = st["extend_launches"]
+            achieved = st["extend_rays"] * b_ray / (ext_ms * 1e-3) / 1e9
+            out["roofline"] = {
+                "kernel": "k_traverse<nearest> (extend)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "bytes_per_ray": b_ray,
+                "inner_nodes_per_ray": nodes_per_ray,
+                "tri_tests_per_ray": tris_per_ray,
+                "launches": launches,
+                "avg_launch_ms": ext_ms / max(launches, 1),
+                "compulsory_hbm_frac": st["extend_rays"] * 48.0 / (ext_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(obj, W, H, args.max_bounces)
+        if args.save:
+            img = pt.to_rgb8(accum.cpu().numpy().reshape(H, W, 3), int(samples / (W * H)))
+            pt.write_png(args.save, img)
+    dev.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out))
+
+
+def cpu_baseline(obj, W, H, max_bounces):
+    """The oracle (CPU restatement of the reference renderer, its T-threads x N-iterations scheme) on a
+    bounded sample of the same workload: full frame, one iteration per thread."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as orc
+
+    cores = min(16, os.cpu_count() or 1)
+    ref = orc.Scene(obj, max_bounces=max_bounces)
+    _, secs, st = ref.render(W, H, threads=cores, iterations_per_thread=1, mode=0, seed=1, stats=True)
+    return {
+        "value": cores * W * H / secs,
+        "unit": "samples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%dx%d full frame, -t %d -n 1 (%d spp), sequential per-thread sampler; %.1f s" % (W, H, cores, cores, secs),
+        "extend_mrays_per_s": st["extend_rays"] / secs / 1e6,
+        "rays_per_s": (st["extend_rays"] + st["shadow_rays"]) / secs,
+    }
+
+
+if __name__ == "__main__":
+    main()

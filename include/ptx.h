@@ -120,6 +120,7 @@ typedef struct ptx_counters {
     uint64_t extend_inner_nodes, extend_tri_tests;
     uint64_t shadow_inner_nodes, shadow_tri_tests;
     uint64_t samples; /* pixel samples completed */
+    uint64_t extend_launches, shadow_launches; /* kernel launches of each traversal class */
     double extend_ms, shadow_ms, shade_ms, generate_ms, total_ms; /* only with PTX_FLAG_TIME_KERNELS */
 } ptx_counters;
 

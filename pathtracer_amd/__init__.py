@@ -87,7 +87,7 @@ class Counters(C.Structure):
     _fields_ = [("extend_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("extend_inner_nodes", C.c_uint64), ("extend_tri_tests", C.c_uint64),
                 ("shadow_inner_nodes", C.c_uint64), ("shadow_tri_tests", C.c_uint64),
-                ("samples", C.c_uint64),
+                ("samples", C.c_uint64), ("extend_launches", C.c_uint64), ("shadow_launches", C.c_uint64),
                 ("extend_ms", C.c_double), ("shadow_ms", C.c_double), ("shade_ms", C.c_double),
                 ("generate_ms", C.c_double), ("total_ms", C.c_double)]
 

@@ -519,6 +519,7 @@ struct ptx_scene {
     DevBuf<unsigned long long> totals;
     uint64_t samples_done = 0;
     uint64_t batch_extend_rays = 0, batch_shadow_rays = 0;  // rays of the *_batch entry points
+    uint64_t extend_launches = 0, shadow_launches = 0;
 
     // kernel timing (PTX_FLAG_TIME_KERNELS)
     struct Stamp {
@@ -749,6 +750,7 @@ int ptx_intersect_batch_device(ptx_scene* sc, const ptx_ray* d_rays, size_t n, p
     if (n > 0xFFFFFFFFull) return fail(PTX_E_LIMIT, "ptx_intersect_batch_device: more than 2^32-1 rays in one call");
     Timed tm(sc, (hipStream_t)stream, KC_EXTEND);
     sc->batch_extend_rays += n;
+    ++sc->extend_launches;
     return launch_traverse<false>(sc, d_rays, nullptr, (uint32_t)n, d_hits, nullptr, sc->totals.p + 2, (hipStream_t)stream);
 }
 
@@ -760,6 +762,7 @@ int ptx_occluded_batch_device(ptx_scene* sc, const ptx_ray* d_rays, size_t n, ui
     if (n > 0xFFFFFFFFull) return fail(PTX_E_LIMIT, "ptx_occluded_batch_device: more than 2^32-1 rays in one call");
     Timed tm(sc, (hipStream_t)stream, KC_SHADOW);
     sc->batch_shadow_rays += n;
+    ++sc->shadow_launches;
     return launch_traverse<true>(sc, d_rays, nullptr, (uint32_t)n, nullptr, d_out, sc->totals.p + 4, (hipStream_t)stream);
 }
 
@@ -804,7 +807,10 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         if (S > 64) S = 64;
     }
     while ((uint64_t)S * n_pixels > (1ull << 28)) S = (S + 1) / 2;  // path ids are 32-bit; keep slots < 2^28
-    if (S > sample_count && sample_count > 0) S = sample_count;
+    if (sample_count > 0) {  // equal-sized batches: ceil(count / ceil(count / S))
+        const uint32_t n_batches = (sample_count + S - 1) / S;
+        S = (sample_count + n_batches - 1) / n_batches;
+    }
     int rc = ensure_render_state(sc, (size_t)S * n_pixels);
     if (rc) return rc;
 
@@ -843,6 +849,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         for (uint32_t b = 1; b <= B; ++b) {
             {
                 Timed tm(sc, stream, KC_EXTEND);
+                ++sc->extend_launches;
                 rc = launch_traverse<false>(sc, st.rays[(b - 1) & 1], st.ext_counts + (b - 1), 0, st.hits, nullptr,
                                             sc->totals.p + 2, stream);
                 if (rc) return rc;
@@ -853,6 +860,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
             }
             if (L > 0) {
                 Timed tm(sc, stream, KC_SHADOW);
+                ++sc->shadow_launches;
                 if (count) k_shadow<true><<<grid, BLOCK, 0, stream>>>(sc->dev, st, b);
                 else k_shadow<false><<<grid, BLOCK, 0, stream>>>(sc->dev, st, b);
             }
@@ -914,6 +922,8 @@ int ptx_stats(ptx_scene* sc, ptx_counters* out) {
     out->shadow_inner_nodes = t[4];
     out->shadow_tri_tests = t[5];
     out->samples = sc->samples_done;
+    out->extend_launches = sc->extend_launches;
+    out->shadow_launches = sc->shadow_launches;
     out->generate_ms = sc->class_ms[KC_GENERATE];
     out->extend_ms = sc->class_ms[KC_EXTEND];
     out->shade_ms = sc->class_ms[KC_SHADE];
@@ -932,6 +942,7 @@ int ptx_stats_reset(ptx_scene* sc) {
     sc->total_ms = 0;
     sc->samples_done = 0;
     sc->batch_extend_rays = sc->batch_shadow_rays = 0;
+    sc->extend_launches = sc->shadow_launches = 0;
     return PTX_OK;
 }
 
