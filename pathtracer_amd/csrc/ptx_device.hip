@@ -60,12 +60,13 @@ struct RenderState {
     ptx_hit* hits;
     float4* transport;
     float4* radiance;
-    float4* sh_origin;   // {point_above.xyz, bits(pid)}
-    float4* sh_T;        // {transport before this bounce's update, 0}
-    float4* sh_dir;      // [i * n_lights + l] {target - origin, 0}
+    ptx_ray* sh_rays;    // [i * n_lights + l] shadow ray: origin point_above, direction target - origin, t in [0,1]
+    float4* sh_T;        // [i] {transport before this bounce's update, bits(pid)}
     float4* sh_contrib;  // [i * n_lights + l] {bsdf * emitted * |cos|, 0}
-    uint32_t* ext_counts;  // [max_bounces + 1]
-    uint32_t* sh_counts;   // [max_bounces]
+    uint8_t* sh_occ;     // [i * n_lights + l] 1 = occluded
+    uint32_t* ext_counts;  // [max_bounces + 1] extend queue lengths
+    uint32_t* sh_counts;   // [max_bounces]     shadow queue lengths (paths; x n_lights rays)
+    uint32_t* cursors;     // [2 * max_bounces] work cursors of the persistent traversal launches
     unsigned long long* totals;  // extend rays, shadow rays, ext inner, ext tris, sh inner, sh tris
     ptx_pinhole cam;
     uint64_t seed;
@@ -121,35 +122,172 @@ __device__ inline void wave_add(unsigned long long* dst, uint32_t v) {
 }
 
 // ------------------------------------------------------------------------------------------ kernels
+// Persistent "while-while" traversal with lane refill.
+//   * every wave owns a cursor window [lo,hi) of the ray array, taken CHUNK rays at a time with ONE
+//     atomic on the launch's cursor; lanes whose ray has finished are refilled from the window as soon
+//     as REFILL_IDLE lanes of the wave are idle, so a long ray never holds 63 idle lanes hostage;
+//   * inner loop 1 walks inner nodes until every live lane stands on a leaf, inner loop 2 tests the
+//     leaf's triangles: lanes do the same kind of work at the same time;
+//   * the traversal stack (far child, t_split) lives in LDS for the first LDS_DEPTH levels
+//     (ds_write_b64 / ds_read_b64, conflict-free: [level][thread]) and in a per-thread global spill
+//     area beyond that (the reference allows 25 levels, kdtree/src/lib.rs:16).
+// Decisions per ray are exactly those of kd_traverse() in traverse.hpp (= KdNode::intersect).
+constexpr int LDS_DEPTH = 10;
+constexpr uint32_t REFILL_IDLE = 16;
+
+struct TravArgs {
+    const uint2* nodes;
+    const uint32_t* leaf_idx;
+    const TriRec* tris;
+    const ptx_ray* rays;
+    const uint32_t* count_ptr;  // device-side ray count (x count_scale), or NULL to use fixed_count
+    uint32_t count_scale, fixed_count;
+    ptx_hit* hits;   // nearest-hit output (ANY == false)
+    uint8_t* occ;    // occlusion output    (ANY == true)
+    uint32_t* cursor;  // zero before the launch
+    uint2* spill;      // [(PTX_MAX_DEPTH - LDS_DEPTH) * spill_stride]
+    uint32_t spill_stride;
+    unsigned long long* work;  // [2] inner nodes, triangle tests (COUNT)
+};
+
 template <bool ANY, bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_traverse(const ptx_kdnode* __restrict__ nodes,
-                                                    const uint32_t* __restrict__ leaf_idx,
-                                                    const TriRec* __restrict__ tris,
-                                                    const ptx_ray* __restrict__ rays,
-                                                    const uint32_t* __restrict__ count_ptr, uint32_t fixed_count,
-                                                    ptx_hit* __restrict__ hits, uint8_t* __restrict__ occluded,
-                                                    unsigned long long* work /* [2]: inner, tris */) {
-    const uint32_t count = count_ptr ? *count_ptr : fixed_count;
-    WorkCount wc{0, 0};
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
-        const float4 a = reinterpret_cast<const float4*>(rays)[2 * (size_t)i];
-        const float4 b = reinterpret_cast<const float4*>(rays)[2 * (size_t)i + 1];
-        ptx_hit h;
-        kd_traverse<ANY, COUNT>(nodes, leaf_idx, tris, a.x, a.y, a.z, b.x, b.y, b.z, a.w, b.w, h, wc);
-        if (ANY) {
-            occluded[i] = h.index != PTX_MISS ? 1 : 0;
-        } else {
-            uint4 o;
-            o.x = h.index;
-            o.y = f2u(h.t);
-            o.z = f2u(h.u);
-            o.w = f2u(h.v);
-            reinterpret_cast<uint4*>(hits)[i] = o;
+__global__ __launch_bounds__(BLOCK) void k_traverse(TravArgs a) {
+    __shared__ uint2 s_stack[LDS_DEPTH][BLOCK];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t gtid = blockIdx.x * BLOCK + tid;
+    const uint32_t count = a.count_ptr ? *a.count_ptr * a.count_scale : a.fixed_count;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // window size: ~4 windows per wave over the launch, 64..512 rays, multiple of 64
+    uint32_t chunk = count / (gridDim.x * WAVES * 4u);
+    chunk = chunk < 64u ? 64u : (chunk > 512u ? 512u : (chunk & ~63u));
+    uint32_t lo = 0, hi = 0;
+    bool drained = false;  // the launch's cursor has passed `count`
+    bool have = false;
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, t_end = 0, t1 = 0, t2 = 0;
+    uint32_t node = 0, ridx = 0;
+    int sp = 0;
+    uint32_t n_inner = 0, n_tris = 0;
+
+    for (;;) {
+        // ---- refill idle lanes from the wave's window
+        for (;;) {
+            const unsigned long long idle = __ballot(!have);
+            if (!idle) break;
+            if (lo >= hi) {
+                if (drained) break;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(a.cursor, chunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= count) {
+                    drained = true;
+                    break;
+                }
+                lo = base;
+                hi = base + chunk < count ? base + chunk : count;
+            }
+            const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            const uint32_t avail = hi - lo;
+            if (!have && rank < avail) {
+                ridx = lo + rank;
+                const float4 ra = reinterpret_cast<const float4*>(a.rays)[2 * (size_t)ridx];
+                const float4 rb = reinterpret_cast<const float4*>(a.rays)[2 * (size_t)ridx + 1];
+                ox = ra.x, oy = ra.y, oz = ra.z, t1 = ra.w;
+                dx = rb.x, dy = rb.y, dz = rb.z, t2 = t_end = rb.w;
+                node = 0;
+                sp = 0;
+                have = true;
+            }
+            lo += n_idle < avail ? n_idle : avail;
+        }
+        if (!__any(have)) break;
+
+        // ---- traverse until enough lanes have finished to make a refill worthwhile
+        for (;;) {
+            uint2 nd = make_uint2(0u, 3u);
+            while (have) {  // inner nodes: kdtree/src/lib.rs:105-129
+                nd = a.nodes[node];
+                const uint32_t kind = nd.y & 3u;
+                if (kind == 3u) break;
+                if (COUNT) ++n_inner;
+                const float dist = u2f(nd.x);
+                const float da = pick(dx, dy, dz, kind);
+                const float oa = pick(ox, oy, oz, kind);
+                const uint32_t left = node + 1u, right = nd.y >> 2;
+                if (da == 0.0f) {
+                    node = oa <= dist ? left : right;
+                } else {
+                    const float t = (dist - oa) / da;
+                    const bool fwd = da >= 0.0f;
+                    const uint32_t near_n = fwd ? left : right;
+                    const uint32_t far_n = fwd ? right : left;
+                    if (t > t2) {
+                        node = near_n;
+                    } else if (t < t1) {
+                        node = far_n;
+                    } else {
+                        const uint2 e = make_uint2(far_n, f2u(t));
+                        if (sp < LDS_DEPTH) s_stack[sp][tid] = e;
+                        else a.spill[(size_t)(sp - LDS_DEPTH) * a.spill_stride + gtid] = e;
+                        ++sp;
+                        node = near_n;
+                        t2 = t;
+                    }
+                }
+            }
+            if (have) {  // leaf: kdtree/src/lib.rs:88-103, geometry/src/geometry.rs:176-196
+                const uint32_t n = nd.y >> 2, off = nd.x;
+                bool found = false;
+                float bt = 0.0f, bu = 0.0f, bv = 0.0f;
+                uint32_t bi = PTX_MISS;
+                for (uint32_t i = 0; i < n; ++i) {
+                    const uint32_t idx = a.leaf_idx[off + i];
+                    if (COUNT) ++n_tris;
+                    float t, u, v;
+                    if (!tri_test(a.tris[idx], ox, oy, oz, dx, dy, dz, t, u, v)) continue;
+                    if (!(t1 <= t && t <= t2)) continue;
+                    if (!found || !(bt <= t)) {
+                        found = true;
+                        bt = t, bu = u, bv = v, bi = idx;
+                        if (ANY) break;
+                    }
+                }
+                bool done = found;
+                if (!found) {
+                    if (t2 == t_end || sp == 0) {
+                        done = true;
+                    } else {
+                        --sp;
+                        const uint2 e = sp < LDS_DEPTH ? s_stack[sp][tid]
+                                                       : a.spill[(size_t)(sp - LDS_DEPTH) * a.spill_stride + gtid];
+                        node = e.x;
+                        t1 = u2f(e.y);
+                        if (sp == 0) {
+                            t2 = t_end;
+                        } else {
+                            const uint2 below = sp - 1 < LDS_DEPTH ? s_stack[sp - 1][tid]
+                                                                   : a.spill[(size_t)(sp - 1 - LDS_DEPTH) * a.spill_stride + gtid];
+                            t2 = u2f(below.y);
+                        }
+                    }
+                }
+                if (done) {
+                    if (ANY) {
+                        a.occ[ridx] = found ? 1 : 0;
+                    } else {
+                        reinterpret_cast<uint4*>(a.hits)[ridx] = make_uint4(bi, f2u(bt), f2u(bu), f2u(bv));
+                    }
+                    have = false;
+                }
+            }
+            const uint32_t live = (uint32_t)__popcll(__ballot(have));
+            if (live == 0) break;
+            if (!(drained && lo >= hi) && live <= 64u - REFILL_IDLE) break;
         }
     }
     if (COUNT) {
-        wave_add(&work[0], wc.inner);
-        wave_add(&work[1], wc.tris);
+        wave_add(&a.work[0], n_inner);
+        wave_add(&a.work[1], n_tris);
     }
 }
 
@@ -379,11 +517,12 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, ui
         if (n_lights > 0) {
             const uint32_t slot_s = block_slot(emit_shadow, &st.sh_counts[bounce - 1u], lds);
             if (emit_shadow) {
-                st.sh_origin[slot_s] = make_float4(point_above.x, point_above.y, point_above.z, u2f(pid));
-                st.sh_T[slot_s] = make_float4(T_old.x, T_old.y, T_old.z, 0.0f);
+                st.sh_T[slot_s] = make_float4(T_old.x, T_old.y, T_old.z, u2f(pid));
                 for (uint32_t l = 0; l < n_lights; ++l) {
-                    st.sh_dir[(size_t)slot_s * n_lights + l] = make_float4(sh_dir[l].x, sh_dir[l].y, sh_dir[l].z, 0.0f);
-                    st.sh_contrib[(size_t)slot_s * n_lights + l] = make_float4(sh_c[l].x, sh_c[l].y, sh_c[l].z, 0.0f);
+                    const size_t j = (size_t)slot_s * n_lights + l;
+                    reinterpret_cast<float4*>(st.sh_rays)[2 * j] = make_float4(point_above.x, point_above.y, point_above.z, 0.0f);
+                    reinterpret_cast<float4*>(st.sh_rays)[2 * j + 1] = make_float4(sh_dir[l].x, sh_dir[l].y, sh_dir[l].z, 1.0f);
+                    st.sh_contrib[j] = make_float4(sh_c[l].x, sh_c[l].y, sh_c[l].z, 0.0f);
                 }
             }
         }
@@ -391,25 +530,19 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, ui
 }
 
 // Next-event estimation resolve: accumulated_radiance += accumulated_transport * sum over lights of the
-// unoccluded contributions, in MTL light order (pathtracer.rs:68-86).  One path per lane.
-template <bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_shadow(DevScene sc, RenderState st, uint32_t bounce) {
+// unoccluded contributions, in MTL light order (pathtracer.rs:68-86).  One path per lane; the occlusion
+// flags come from the any-hit traversal launch over the shadow-ray queue.
+__global__ __launch_bounds__(BLOCK) void k_resolve(RenderState st, uint32_t bounce, uint32_t n_lights) {
     const uint32_t count = st.sh_counts[bounce - 1u];
-    const uint32_t n_lights = sc.n_lights;
-    WorkCount wc{0, 0};
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
-        const float4 o = st.sh_origin[i];
         const float4 T = st.sh_T[i];
-        const uint32_t pid = f2u(o.w);
+        const uint32_t pid = f2u(T.w);
         V3 incoming = v3(0.0f, 0.0f, 0.0f);
         for (uint32_t l = 0; l < n_lights; ++l) {
-            const float4 d = st.sh_dir[(size_t)i * n_lights + l];
-            ptx_hit h;
-            const bool occ = kd_traverse<true, COUNT>(sc.nodes, sc.leaf_idx, sc.tris, o.x, o.y, o.z, d.x, d.y, d.z,
-                                                      0.0f, 1.0f, h, wc);
+            const size_t j = (size_t)i * n_lights + l;
             V3 c = v3(0.0f, 0.0f, 0.0f);
-            if (!occ) {
-                const float4 cc = st.sh_contrib[(size_t)i * n_lights + l];
+            if (!st.sh_occ[j]) {
+                const float4 cc = st.sh_contrib[j];
                 c = v3(cc.x, cc.y, cc.z);
             }
             incoming = incoming + c;
@@ -419,10 +552,6 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DevScene sc, RenderState st, u
         R.y = R.y + T.y * incoming.y;
         R.z = R.z + T.z * incoming.z;
         st.radiance[pid] = R;
-    }
-    if (COUNT) {
-        wave_add(&st.totals[4], wc.inner);
-        wave_add(&st.totals[5], wc.tris);
     }
 }
 
@@ -514,7 +643,11 @@ struct ptx_scene {
     DevBuf<ptx_ray> rays[2];
     DevBuf<uint32_t> pids[2];
     DevBuf<ptx_hit> hits;
-    DevBuf<float4> transport, radiance, sh_origin, sh_T, sh_dir, sh_contrib;
+    DevBuf<float4> transport, radiance, sh_T, sh_contrib;
+    DevBuf<ptx_ray> sh_rays;
+    DevBuf<uint8_t> sh_occ;
+    DevBuf<uint2> spill;
+    DevBuf<uint32_t> batch_cursor;
     DevBuf<uint32_t> counts;
     DevBuf<unsigned long long> totals;
     uint64_t samples_done = 0;
@@ -601,11 +734,11 @@ int ensure_render_state(ptx_scene* sc, size_t paths) {
     HIP_TRY(sc->hits.ensure(paths));
     HIP_TRY(sc->transport.ensure(paths));
     HIP_TRY(sc->radiance.ensure(paths));
-    HIP_TRY(sc->sh_origin.ensure(paths));
     HIP_TRY(sc->sh_T.ensure(paths));
-    HIP_TRY(sc->sh_dir.ensure(paths * L));
+    HIP_TRY(sc->sh_rays.ensure(paths * L));
     HIP_TRY(sc->sh_contrib.ensure(paths * L));
-    HIP_TRY(sc->counts.ensure(2 * (size_t)B + 2));
+    HIP_TRY(sc->sh_occ.ensure(paths * L));
+    HIP_TRY(sc->counts.ensure(4 * (size_t)B + 2));
     if (!sc->totals.p) {
         HIP_TRY(sc->totals.ensure(8));
         HIP_TRY(hipMemset(sc->totals.p, 0, 8 * sizeof(unsigned long long)));
@@ -624,20 +757,30 @@ int check_scene(ptx_scene* sc, const char* who) {
 }
 
 template <bool ANY>
-int launch_traverse(ptx_scene* sc, const ptx_ray* d_rays, const uint32_t* d_count, uint32_t n, ptx_hit* d_hits,
-                    uint8_t* d_occ, unsigned long long* work, hipStream_t stream) {
+int launch_traverse(ptx_scene* sc, const ptx_ray* d_rays, const uint32_t* d_count, uint32_t count_scale, uint32_t n,
+                    ptx_hit* d_hits, uint8_t* d_occ, uint32_t* d_cursor, unsigned long long* work, hipStream_t stream) {
     const bool count = (sc->flags & PTX_FLAG_COUNT_WORK) != 0 && work;
-    int grid = sc->grid;
+    TravArgs a{};
+    a.nodes = reinterpret_cast<const uint2*>(sc->dev.nodes);
+    a.leaf_idx = sc->dev.leaf_idx;
+    a.tris = sc->dev.tris;
+    a.rays = d_rays;
+    a.count_ptr = d_count;
+    a.count_scale = count_scale;
+    a.fixed_count = n;
+    a.hits = d_hits;
+    a.occ = d_occ;
+    a.cursor = d_cursor;
+    a.spill = sc->spill.p;
+    a.spill_stride = (uint32_t)sc->grid * BLOCK;
+    a.work = work;
+    int grid = sc->grid;  // the spill area is sized for this many threads: never launch more
     if (!d_count) {
-        int need = (int)((n + BLOCK - 1) / BLOCK);
+        int need = (int)((n + 63) / 64 + WAVES - 1) / WAVES;
         if (need < grid) grid = need > 0 ? need : 1;
     }
-    if (count)
-        k_traverse<ANY, true><<<grid, BLOCK, 0, stream>>>(sc->dev.nodes, sc->dev.leaf_idx, sc->dev.tris, d_rays, d_count,
-                                                          n, d_hits, d_occ, work);
-    else
-        k_traverse<ANY, false><<<grid, BLOCK, 0, stream>>>(sc->dev.nodes, sc->dev.leaf_idx, sc->dev.tris, d_rays,
-                                                           d_count, n, d_hits, d_occ, nullptr);
+    if (count) k_traverse<ANY, true><<<grid, BLOCK, 0, stream>>>(a);
+    else k_traverse<ANY, false><<<grid, BLOCK, 0, stream>>>(a);
     HIP_TRY(hipGetLastError());
     return PTX_OK;
 }
@@ -731,6 +874,8 @@ int ptx_scene_create(const ptx_scene_desc* d, uint32_t flags, ptx_scene** out) {
     sc->dev.max_bounces = d->max_bounces;
     HIP_TRY(sc->totals.ensure(8));
     HIP_TRY(hipMemset(sc->totals.p, 0, 8 * sizeof(unsigned long long)));
+    HIP_TRY(sc->spill.ensure((size_t)(PTX_MAX_DEPTH - LDS_DEPTH) * sc->grid * BLOCK));
+    HIP_TRY(sc->batch_cursor.ensure(1));
     *out = sc.release();
     return PTX_OK;
 }
@@ -751,7 +896,9 @@ int ptx_intersect_batch_device(ptx_scene* sc, const ptx_ray* d_rays, size_t n, p
     Timed tm(sc, (hipStream_t)stream, KC_EXTEND);
     sc->batch_extend_rays += n;
     ++sc->extend_launches;
-    return launch_traverse<false>(sc, d_rays, nullptr, (uint32_t)n, d_hits, nullptr, sc->totals.p + 2, (hipStream_t)stream);
+    HIP_TRY(hipMemsetAsync(sc->batch_cursor.p, 0, sizeof(uint32_t), (hipStream_t)stream));
+    return launch_traverse<false>(sc, d_rays, nullptr, 1, (uint32_t)n, d_hits, nullptr, sc->batch_cursor.p, sc->totals.p + 2,
+                                  (hipStream_t)stream);
 }
 
 int ptx_occluded_batch_device(ptx_scene* sc, const ptx_ray* d_rays, size_t n, uint8_t* d_out, void* stream) {
@@ -763,7 +910,9 @@ int ptx_occluded_batch_device(ptx_scene* sc, const ptx_ray* d_rays, size_t n, ui
     Timed tm(sc, (hipStream_t)stream, KC_SHADOW);
     sc->batch_shadow_rays += n;
     ++sc->shadow_launches;
-    return launch_traverse<true>(sc, d_rays, nullptr, (uint32_t)n, nullptr, d_out, sc->totals.p + 4, (hipStream_t)stream);
+    HIP_TRY(hipMemsetAsync(sc->batch_cursor.p, 0, sizeof(uint32_t), (hipStream_t)stream));
+    return launch_traverse<true>(sc, d_rays, nullptr, 1, (uint32_t)n, nullptr, d_out, sc->batch_cursor.p, sc->totals.p + 4,
+                                 (hipStream_t)stream);
 }
 
 int ptx_intersect_batch(ptx_scene* sc, const ptx_ray* rays, size_t n, ptx_hit* hits) {
@@ -823,17 +972,17 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
     st.hits = sc->hits.p;
     st.transport = sc->transport.p;
     st.radiance = sc->radiance.p;
-    st.sh_origin = sc->sh_origin.p;
+    st.sh_rays = sc->sh_rays.p;
     st.sh_T = sc->sh_T.p;
-    st.sh_dir = sc->sh_dir.p;
     st.sh_contrib = sc->sh_contrib.p;
+    st.sh_occ = sc->sh_occ.p;
     st.ext_counts = sc->counts.p;
     st.sh_counts = sc->counts.p + (B + 1);
+    st.cursors = sc->counts.p + (2 * B + 1);
     st.totals = sc->totals.p;
     st.cam = *cam;
     st.seed = seed;
     st.n_pixels = n_pixels;
-    const bool count = (sc->flags & PTX_FLAG_COUNT_WORK) != 0;
     const int grid = sc->grid;
     auto t0 = std::chrono::steady_clock::now();
 
@@ -841,7 +990,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         const uint32_t ns = sample_count - done < S ? sample_count - done : S;
         st.n_samples = ns;
         st.first_sample = first_sample + done;
-        HIP_TRY(hipMemsetAsync(sc->counts.p, 0, (2 * (size_t)B + 2) * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(sc->counts.p, 0, (4 * (size_t)B + 2) * sizeof(uint32_t), stream));
         {
             Timed tm(sc, stream, KC_GENERATE);
             k_generate<<<grid, BLOCK, 0, stream>>>(st);
@@ -850,8 +999,8 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
             {
                 Timed tm(sc, stream, KC_EXTEND);
                 ++sc->extend_launches;
-                rc = launch_traverse<false>(sc, st.rays[(b - 1) & 1], st.ext_counts + (b - 1), 0, st.hits, nullptr,
-                                            sc->totals.p + 2, stream);
+                rc = launch_traverse<false>(sc, st.rays[(b - 1) & 1], st.ext_counts + (b - 1), 1, 0, st.hits, nullptr,
+                                            st.cursors + 2 * (b - 1), sc->totals.p + 2, stream);
                 if (rc) return rc;
             }
             {
@@ -861,8 +1010,10 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
             if (L > 0) {
                 Timed tm(sc, stream, KC_SHADOW);
                 ++sc->shadow_launches;
-                if (count) k_shadow<true><<<grid, BLOCK, 0, stream>>>(sc->dev, st, b);
-                else k_shadow<false><<<grid, BLOCK, 0, stream>>>(sc->dev, st, b);
+                rc = launch_traverse<true>(sc, st.sh_rays, st.sh_counts + (b - 1), L, 0, nullptr, st.sh_occ,
+                                           st.cursors + 2 * (b - 1) + 1, sc->totals.p + 4, stream);
+                if (rc) return rc;
+                k_resolve<<<grid, BLOCK, 0, stream>>>(st, b, L);
             }
         }
         {
