@@ -6,6 +6,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <map>
 #include <sstream>
 
 #include "restate_wavefront.hpp"
@@ -281,6 +282,53 @@ void orc_brute_intersect(void* h, const void* rays, size_t n, void* hits, int th
                                                        r[i].tmin, r[i].tmax));
         }
     });
+}
+
+// Visits per tree depth (root = depth 0) over a ray batch: sizing aid for caching the top of the tree.
+void orc_depth_histogram(void* h, const void* rays, size_t n, uint64_t* hist32) {
+    Tree* t = (Tree*)h;
+    const RayIn* r = (const RayIn*)rays;
+    std::vector<std::pair<const KdNode*, int>> depth_of;
+    std::map<const KdNode*, int> depth;
+    std::vector<std::pair<const KdNode*, int>> st{{t->root.get(), 0}};
+    while (!st.empty()) {
+        auto [nd, d] = st.back();
+        st.pop_back();
+        depth[nd] = d;
+        if (!nd->is_leaf) {
+            st.push_back({nd->left.get(), d + 1});
+            st.push_back({nd->right.get(), d + 1});
+        }
+    }
+    for (int i = 0; i < 32; ++i) hist32[i] = 0;
+    for (size_t i = 0; i < n; ++i) {
+        Ray ray{{r[i].ox, r[i].oy, r[i].oz}, {r[i].dx, r[i].dy, r[i].dz}};
+        // same walk as kd_intersect, recording node depths
+        struct E { const KdNode* node; float t1, t2; };
+        const KdNode* node = t->root.get();
+        float t1 = r[i].tmin, t2 = r[i].tmax, t_end = r[i].tmax;
+        E stack[MAX_DEPTH];
+        size_t sp = 0;
+        for (;;) {
+            ++hist32[std::min(depth[node], 31)];
+            if (node->is_leaf) {
+                auto res = intersect_closest_geometry(t->triangles, node->indices.begin(), node->indices.end(), ray, t1, t2);
+                if (res || t2 == t_end || sp == 0) break;
+                --sp;
+                node = stack[sp].node; t1 = stack[sp].t1; t2 = stack[sp].t2;
+            } else {
+                auto tt = node->plane.intersect_ray(ray);
+                int axis = node->plane.axis;
+                if (tt) {
+                    const KdNode* nn = ray.direction[axis] >= 0.0f ? node->left.get() : node->right.get();
+                    const KdNode* fn = ray.direction[axis] >= 0.0f ? node->right.get() : node->left.get();
+                    if (*tt > t2) node = nn;
+                    else if (*tt < t1) node = fn;
+                    else { stack[sp++] = {fn, *tt, t2}; node = nn; t2 = *tt; }
+                } else node = ray.origin[axis] <= node->plane.distance ? node->left.get() : node->right.get();
+            }
+        }
+    }
 }
 
 // ---- materials / sampling ---------------------------------------------------------------------

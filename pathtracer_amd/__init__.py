@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libptx_mi355x.so")
+LIB_PATH = os.environ.get("PTX_LIB") or os.path.join(_HERE, "lib", "libptx_mi355x.so")
 
 RAY_DTYPE = np.dtype([("o", "<f4", 3), ("tmin", "<f4"), ("d", "<f4", 3), ("tmax", "<f4")])
 HIT_DTYPE = np.dtype([("index", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
