@@ -215,6 +215,9 @@ int ptx_render_device(ptx_scene* scene, const ptx_pinhole* camera, uint64_t seed
 /* Samples kept in flight per launch batch (default chosen from the image size). */
 int ptx_set_batch_samples(ptx_scene* scene, uint32_t samples_per_batch);
 
+/* Queue lengths of the most recent render batch: extend_counts[b] / shadow_counts[b] = rays of bounce b+1
+ * (shadow counts are paths; multiply by the number of lights).  n = capacity of each array. */
+int ptx_last_batch_counts(ptx_scene* scene, uint32_t* extend_counts, uint32_t* shadow_counts, uint32_t n);
 int ptx_stats(ptx_scene* scene, ptx_counters* out);
 int ptx_stats_reset(ptx_scene* scene);
 

@@ -345,6 +345,12 @@ class DeviceScene:
         _check(lib().ptx_stats(self._h, C.byref(c)))
         return c.as_dict()
 
+    def last_batch_counts(self):
+        n = max(self.max_bounces, 1)
+        e, s = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        _check(lib().ptx_last_batch_counts(self._h, _ptr(e), _ptr(s), n))
+        return e, s
+
     def stats_reset(self):
         _check(lib().ptx_stats_reset(self._h))
 

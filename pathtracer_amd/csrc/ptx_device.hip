@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <chrono>
 #include <memory>
@@ -152,7 +153,7 @@ __device__ inline void wave_add(unsigned long long* dst, uint32_t v) {
 #define PTX_LDS_DEPTH 8
 #endif
 #ifndef PTX_TOP_NODES
-#define PTX_TOP_NODES 1024
+#define PTX_TOP_NODES 0
 #endif
 #ifndef PTX_REFILL_IDLE
 #define PTX_REFILL_IDLE 16
@@ -258,42 +259,44 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
         for (;;) {
             bool leaf_end = false;
             const bool walking = have && tri_i == tri_n;
-            if (walking) {  // node visit: kdtree/src/lib.rs:105-129
-                const uint2 nd = node < top_count ? s_top[node] : a.nodes[node];
+            if (walking) {  // node visit, kdtree/src/lib.rs:105-129, written with selects instead of branches
+#if PTX_TOP_NODES > 0
+                uint2 nd;
+                if (node < top_count) nd = s_top[node];
+                else nd = a.nodes[node];
+#else
+                const uint2 nd = a.nodes[node];
+#endif
                 const uint32_t kind = nd.y & 3u;
-                if (kind != 3u) {
-                    if (COUNT) ++n_inner;
-                    const float dist = u2f(nd.x);
-                    const float da = pick(dx, dy, dz, kind);
-                    const float oa = pick(ox, oy, oz, kind);
-                    const uint32_t left = nd.y >> 2, right = left + 1u;
-                    if (da == 0.0f) {
-                        node = oa <= dist ? left : right;
-                    } else {
-                        const float t = (dist - oa) / da;
-                        const bool fwd = da >= 0.0f;
-                        const uint32_t near_n = fwd ? left : right;
-                        const uint32_t far_n = fwd ? right : left;
-                        if (t > t2) {
-                            node = near_n;
-                        } else if (t < t1) {
-                            node = far_n;
-                        } else {
-                            const uint2 e = make_uint2(far_n, f2u(t));
-                            if (sp < LDS_DEPTH) s_stack[sp][tid] = e;
-                            else a.spill[(size_t)(sp - LDS_DEPTH) * a.spill_stride + gtid] = e;
-                            ++sp;
-                            node = near_n;
-                            t2 = t;
-                        }
-                    }
-                } else {  // leaf entry (kdtree/src/lib.rs:88-94); an empty leaf is resolved at once
-                    tri_n = nd.y >> 2;
-                    tri_off = nd.x;
-                    tri_i = 0;
-                    bi = PTX_MISS;
-                    leaf_end = tri_n == 0;
+                const bool is_leaf = kind == 3u;
+                if (COUNT) n_inner += is_leaf ? 0u : 1u;
+                const float dist = u2f(nd.x);
+                const float da = pick(dx, dy, dz, kind);
+                const float oa = pick(ox, oy, oz, kind);
+                const uint32_t left = nd.y >> 2, right = left + 1u;
+                const float t = (dist - oa) / da;  // unused (selected away) when da == 0 or on a leaf
+                const bool fwd = da >= 0.0f;
+                const uint32_t near_n = fwd ? left : right;
+                const uint32_t far_n = fwd ? right : left;
+                const bool parallel = da == 0.0f;
+                const bool only_near = t > t2, only_far = t < t1;
+                const bool push = !is_leaf && !parallel && !only_near && !only_far;
+                uint32_t next = only_far ? far_n : near_n;
+                next = parallel ? (oa <= dist ? left : right) : next;
+                if (push) {
+                    const uint2 e = make_uint2(far_n, f2u(t));
+                    if (sp < LDS_DEPTH) s_stack[sp][tid] = e;
+                    else a.spill[(size_t)(sp - LDS_DEPTH) * a.spill_stride + gtid] = e;
                 }
+                sp += push ? 1 : 0;
+                t2 = push ? t : t2;
+                node = is_leaf ? node : next;
+                // leaf entry (kdtree/src/lib.rs:88-94); an empty leaf is resolved at once
+                tri_n = is_leaf ? nd.y >> 2 : tri_n;
+                tri_off = is_leaf ? nd.x : tri_off;
+                tri_i = is_leaf ? 0u : tri_i;
+                bi = is_leaf ? PTX_MISS : bi;
+                leaf_end = is_leaf && (nd.y >> 2) == 0u;
             }
             const unsigned long long in_leaf = __ballot(have && tri_i < tri_n);
             const unsigned long long can_walk = __ballot(have && tri_i == tri_n && !leaf_end);
@@ -711,15 +714,33 @@ struct ptx_scene {
     uint32_t batch_samples = 0;  // 0 = choose from the image size
     size_t cap_paths = 0;
     uint32_t cap_lights = 0, cap_bounces = 0;
-    DevBuf<ptx_ray> rays[2];
-    DevBuf<uint32_t> pids[2];
-    DevBuf<ptx_hit> hits;
-    DevBuf<float4> transport, radiance, sh_T, sh_contrib;
-    DevBuf<ptx_ray> sh_rays;
-    DevBuf<uint8_t> sh_occ;
-    DevBuf<uint2> spill;
+    // One pipeline = the queues and state of one sample batch in flight on its own stream.  Batches are
+    // independent until their accumulate step, so several run concurrently: the long-ray tails of the
+    // late bounces of one batch (a few waves busy, the rest of the chip idle) overlap with the wide early
+    // bounces of another.
+    struct Pipe {
+        hipStream_t stream = nullptr;
+        hipEvent_t ev_accum = nullptr, ev_join = nullptr;
+        DevBuf<ptx_ray> rays[2];
+        DevBuf<uint32_t> pids[2];
+        DevBuf<ptx_hit> hits;
+        DevBuf<float4> transport, radiance, sh_T, sh_contrib;
+        DevBuf<ptx_ray> sh_rays;
+        DevBuf<uint8_t> sh_occ;
+        DevBuf<uint2> spill;
+        DevBuf<uint32_t> counts;
+        ~Pipe() {
+            if (ev_accum) (void)hipEventDestroy(ev_accum);
+            if (ev_join) (void)hipEventDestroy(ev_join);
+            if (stream) (void)hipStreamDestroy(stream);
+        }
+    };
+    std::vector<std::unique_ptr<Pipe>> pipes;
+    uint32_t n_pipes = 2;
+    int last_pipe = 0;
+    hipEvent_t ev_fork = nullptr;
+    DevBuf<uint2> spill;  // of the *_batch entry points
     DevBuf<uint32_t> batch_cursor;
-    DevBuf<uint32_t> counts;
     DevBuf<unsigned long long> totals;
     uint64_t samples_done = 0;
     uint64_t batch_extend_rays = 0, batch_shadow_rays = 0;  // rays of the *_batch entry points
@@ -741,6 +762,7 @@ struct ptx_scene {
     DevBuf<float> stage_accum;
 
     ~ptx_scene() {
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
         for (auto& s : stamps) {
             (void)hipEventDestroy(s.a);
             (void)hipEventDestroy(s.b);
@@ -797,26 +819,40 @@ void resolve_stamps(ptx_scene* sc) {
 int ensure_render_state(ptx_scene* sc, size_t paths) {
     const uint32_t L = sc->dev.n_lights ? sc->dev.n_lights : 1u;
     const uint32_t B = sc->dev.max_bounces;
-    if (paths <= sc->cap_paths && L <= sc->cap_lights && B <= sc->cap_bounces) return PTX_OK;
-    for (int q = 0; q < 2; ++q) {
-        HIP_TRY(sc->rays[q].ensure(paths));
-        HIP_TRY(sc->pids[q].ensure(paths));
+    if (sc->pipes.size() == sc->n_pipes && paths <= sc->cap_paths && L <= sc->cap_lights && B <= sc->cap_bounces)
+        return PTX_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    if (!sc->ev_fork) HIP_TRY(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
+    sc->pipes.resize(sc->n_pipes);
+    for (auto& up : sc->pipes) {
+        if (!up) {
+            up = std::make_unique<ptx_scene::Pipe>();
+            HIP_TRY(hipStreamCreateWithFlags(&up->stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&up->ev_accum, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&up->ev_join, hipEventDisableTiming));
+            HIP_TRY(up->spill.ensure((size_t)(PTX_MAX_DEPTH - LDS_DEPTH) * sc->tgrid * TBLOCK));
+        }
+        ptx_scene::Pipe& p = *up;
+        for (int q = 0; q < 2; ++q) {
+            HIP_TRY(p.rays[q].ensure(paths));
+            HIP_TRY(p.pids[q].ensure(paths));
+        }
+        HIP_TRY(p.hits.ensure(paths));
+        HIP_TRY(p.transport.ensure(paths));
+        HIP_TRY(p.radiance.ensure(paths));
+        HIP_TRY(p.sh_T.ensure(paths));
+        HIP_TRY(p.sh_rays.ensure(paths * L));
+        HIP_TRY(p.sh_contrib.ensure(paths * L));
+        HIP_TRY(p.sh_occ.ensure(paths * L));
+        HIP_TRY(p.counts.ensure(4 * (size_t)B + 2));
     }
-    HIP_TRY(sc->hits.ensure(paths));
-    HIP_TRY(sc->transport.ensure(paths));
-    HIP_TRY(sc->radiance.ensure(paths));
-    HIP_TRY(sc->sh_T.ensure(paths));
-    HIP_TRY(sc->sh_rays.ensure(paths * L));
-    HIP_TRY(sc->sh_contrib.ensure(paths * L));
-    HIP_TRY(sc->sh_occ.ensure(paths * L));
-    HIP_TRY(sc->counts.ensure(4 * (size_t)B + 2));
     if (!sc->totals.p) {
         HIP_TRY(sc->totals.ensure(8));
         HIP_TRY(hipMemset(sc->totals.p, 0, 8 * sizeof(unsigned long long)));
     }
-    sc->cap_paths = paths;
-    sc->cap_lights = L;
-    sc->cap_bounces = B;
+    sc->cap_paths = paths > sc->cap_paths ? paths : sc->cap_paths;
+    sc->cap_lights = L > sc->cap_lights ? L : sc->cap_lights;
+    sc->cap_bounces = B > sc->cap_bounces ? B : sc->cap_bounces;
     return PTX_OK;
 }
 
@@ -886,7 +922,8 @@ void relayout_nodes(const ptx_kdnode* in, uint32_t n_nodes, const uint32_t* leaf
 
 template <bool ANY>
 int launch_traverse(ptx_scene* sc, const ptx_ray* d_rays, const uint32_t* d_count, uint32_t count_scale, uint32_t n,
-                    ptx_hit* d_hits, uint8_t* d_occ, uint32_t* d_cursor, unsigned long long* work, hipStream_t stream) {
+                    ptx_hit* d_hits, uint8_t* d_occ, uint32_t* d_cursor, uint2* d_spill, unsigned long long* work,
+                    hipStream_t stream) {
     const bool count = (sc->flags & PTX_FLAG_COUNT_WORK) != 0 && work;
     TravArgs a{};
     a.nodes = sc->dev_nodes.p;
@@ -900,7 +937,7 @@ int launch_traverse(ptx_scene* sc, const ptx_ray* d_rays, const uint32_t* d_coun
     a.hits = d_hits;
     a.occ = d_occ;
     a.cursor = d_cursor;
-    a.spill = sc->spill.p;
+    a.spill = d_spill;
     a.spill_stride = (uint32_t)sc->tgrid * TBLOCK;
     a.work = work;
     int grid = sc->tgrid;  // the spill area is sized for this many threads: never launch more
@@ -950,6 +987,10 @@ int ptx_scene_create(const ptx_scene_desc* d, uint32_t flags, ptx_scene** out) {
     sc->grid = prop.multiProcessorCount * 8;
     sc->tgrid = prop.multiProcessorCount * PTX_BLOCKS_PER_CU;  // sized so that the LDS of a CU is filled
     sc->flags = flags;
+    if (const char* e = getenv("PTX_PIPES")) {
+        int k = atoi(e);
+        if (k >= 1 && k <= 8) sc->n_pipes = (uint32_t)k;
+    }
     sc->n_triangles = d->n_triangles;
     sc->n_nodes = d->n_nodes;
     sc->shading = shading;
@@ -1032,8 +1073,8 @@ int ptx_intersect_batch_device(ptx_scene* sc, const ptx_ray* d_rays, size_t n, p
     sc->batch_extend_rays += n;
     ++sc->extend_launches;
     HIP_TRY(hipMemsetAsync(sc->batch_cursor.p, 0, sizeof(uint32_t), (hipStream_t)stream));
-    return launch_traverse<false>(sc, d_rays, nullptr, 1, (uint32_t)n, d_hits, nullptr, sc->batch_cursor.p, sc->totals.p + 2,
-                                  (hipStream_t)stream);
+    return launch_traverse<false>(sc, d_rays, nullptr, 1, (uint32_t)n, d_hits, nullptr, sc->batch_cursor.p, sc->spill.p,
+                                  sc->totals.p + 2, (hipStream_t)stream);
 }
 
 int ptx_occluded_batch_device(ptx_scene* sc, const ptx_ray* d_rays, size_t n, uint8_t* d_out, void* stream) {
@@ -1046,8 +1087,8 @@ int ptx_occluded_batch_device(ptx_scene* sc, const ptx_ray* d_rays, size_t n, ui
     sc->batch_shadow_rays += n;
     ++sc->shadow_launches;
     HIP_TRY(hipMemsetAsync(sc->batch_cursor.p, 0, sizeof(uint32_t), (hipStream_t)stream));
-    return launch_traverse<true>(sc, d_rays, nullptr, 1, (uint32_t)n, nullptr, d_out, sc->batch_cursor.p, sc->totals.p + 4,
-                                 (hipStream_t)stream);
+    return launch_traverse<true>(sc, d_rays, nullptr, 1, (uint32_t)n, nullptr, d_out, sc->batch_cursor.p, sc->spill.p,
+                                 sc->totals.p + 4, (hipStream_t)stream);
 }
 
 int ptx_intersect_batch(ptx_scene* sc, const ptx_ray* rays, size_t n, ptx_hit* hits) {
@@ -1075,7 +1116,7 @@ int ptx_set_batch_samples(ptx_scene* sc, uint32_t samples_per_batch) {
 }
 
 static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uint32_t first_sample,
-                       uint32_t sample_count, float* d_accum, hipStream_t stream, ptx_progress_cb progress,
+                       uint32_t sample_count, float* d_accum, hipStream_t user_stream, ptx_progress_cb progress,
                        void* user) {
     if (!cam || !d_accum) return fail(PTX_E_ARG, "ptx_render: null argument");
     if (!sc->shading) return fail(PTX_E_ARG, "ptx_render: scene was created without shading data");
@@ -1086,7 +1127,9 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
     const uint32_t n_pixels = (uint32_t)n_pixels64;
     uint32_t S = sc->batch_samples;
     if (S == 0) {
-        S = (uint32_t)((6u << 20) / n_pixels);
+        // large batches amortise the long-ray tail of every launch (measured: 5 -> 48 samples in flight at
+        // 1080^2 raises the traversal kernels from 2.5 to 5.5 Grays/s); ~200 B of queue state per path
+        S = (uint32_t)((48u << 20) / n_pixels);
         if (S < 1) S = 1;
         if (S > 64) S = 64;
     }
@@ -1099,33 +1142,40 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
     if (rc) return rc;
 
     const uint32_t B = sc->dev.max_bounces, L = sc->dev.n_lights;
-    RenderState st{};
-    st.rays[0] = sc->rays[0].p;
-    st.rays[1] = sc->rays[1].p;
-    st.pids[0] = sc->pids[0].p;
-    st.pids[1] = sc->pids[1].p;
-    st.hits = sc->hits.p;
-    st.transport = sc->transport.p;
-    st.radiance = sc->radiance.p;
-    st.sh_rays = sc->sh_rays.p;
-    st.sh_T = sc->sh_T.p;
-    st.sh_contrib = sc->sh_contrib.p;
-    st.sh_occ = sc->sh_occ.p;
-    st.ext_counts = sc->counts.p;
-    st.sh_counts = sc->counts.p + (B + 1);
-    st.cursors = sc->counts.p + (2 * B + 1);
-    st.totals = sc->totals.p;
-    st.cam = *cam;
-    st.seed = seed;
-    st.n_pixels = n_pixels;
     const int grid = sc->grid;
     auto t0 = std::chrono::steady_clock::now();
-
-    for (uint32_t done = 0; done < sample_count; done += S) {
+    // fork: the pipelines start after everything already queued on the caller's stream
+    HIP_TRY(hipEventRecord(sc->ev_fork, user_stream));
+    for (auto& p : sc->pipes) HIP_TRY(hipStreamWaitEvent(p->stream, sc->ev_fork, 0));
+    hipEvent_t prev_accum = nullptr;
+    uint32_t batch_no = 0;
+    for (uint32_t done = 0; done < sample_count; done += S, ++batch_no) {
+        ptx_scene::Pipe& p = *sc->pipes[batch_no % sc->pipes.size()];
+        sc->last_pipe = (int)(batch_no % sc->pipes.size());
+        hipStream_t stream = p.stream;
         const uint32_t ns = sample_count - done < S ? sample_count - done : S;
+        RenderState st{};
+        st.rays[0] = p.rays[0].p;
+        st.rays[1] = p.rays[1].p;
+        st.pids[0] = p.pids[0].p;
+        st.pids[1] = p.pids[1].p;
+        st.hits = p.hits.p;
+        st.transport = p.transport.p;
+        st.radiance = p.radiance.p;
+        st.sh_rays = p.sh_rays.p;
+        st.sh_T = p.sh_T.p;
+        st.sh_contrib = p.sh_contrib.p;
+        st.sh_occ = p.sh_occ.p;
+        st.ext_counts = p.counts.p;
+        st.sh_counts = p.counts.p + (B + 1);
+        st.cursors = p.counts.p + (2 * B + 1);
+        st.totals = sc->totals.p;
+        st.cam = *cam;
+        st.seed = seed;
+        st.n_pixels = n_pixels;
         st.n_samples = ns;
         st.first_sample = first_sample + done;
-        HIP_TRY(hipMemsetAsync(sc->counts.p, 0, (4 * (size_t)B + 2) * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(p.counts.p, 0, (4 * (size_t)B + 2) * sizeof(uint32_t), stream));
         {
             Timed tm(sc, stream, KC_GENERATE);
             k_generate<<<grid, BLOCK, 0, stream>>>(st);
@@ -1135,7 +1185,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
                 Timed tm(sc, stream, KC_EXTEND);
                 ++sc->extend_launches;
                 rc = launch_traverse<false>(sc, st.rays[(b - 1) & 1], st.ext_counts + (b - 1), 1, 0, st.hits, nullptr,
-                                            st.cursors + 2 * (b - 1), sc->totals.p + 2, stream);
+                                            st.cursors + 2 * (b - 1), p.spill.p, sc->totals.p + 2, stream);
                 if (rc) return rc;
             }
             {
@@ -1146,16 +1196,20 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
                 Timed tm(sc, stream, KC_SHADOW);
                 ++sc->shadow_launches;
                 rc = launch_traverse<true>(sc, st.sh_rays, st.sh_counts + (b - 1), L, 0, nullptr, st.sh_occ,
-                                           st.cursors + 2 * (b - 1) + 1, sc->totals.p + 4, stream);
+                                           st.cursors + 2 * (b - 1) + 1, p.spill.p, sc->totals.p + 4, stream);
                 if (rc) return rc;
                 k_resolve<<<grid, BLOCK, 0, stream>>>(st, b, L);
             }
         }
+        // samples reach a pixel in index order: this batch's accumulate waits for the previous batch's
+        if (prev_accum) HIP_TRY(hipStreamWaitEvent(stream, prev_accum, 0));
         {
             Timed tm(sc, stream, KC_OTHER);
             k_accumulate<<<grid, BLOCK, 0, stream>>>(st, d_accum);
             k_tally<<<1, 64, 0, stream>>>(st, B, L);
         }
+        HIP_TRY(hipEventRecord(p.ev_accum, stream));
+        prev_accum = p.ev_accum;
         HIP_TRY(hipGetLastError());
         sc->samples_done += (uint64_t)ns * n_pixels;
         if (progress) {
@@ -1163,6 +1217,11 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
             double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             progress(done + ns, secs, user);
         }
+    }
+    // join: the caller's stream continues after every pipeline has drained
+    for (auto& p : sc->pipes) {
+        HIP_TRY(hipEventRecord(p->ev_join, p->stream));
+        HIP_TRY(hipStreamWaitEvent(user_stream, p->ev_join, 0));
     }
     return PTX_OK;
 }
@@ -1189,6 +1248,22 @@ int ptx_render(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uint32_t fi
     HIP_TRY(hipDeviceSynchronize());
     sc->total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     HIP_TRY(hipMemcpy(accum_host, sc->stage_accum.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return PTX_OK;
+}
+
+int ptx_last_batch_counts(ptx_scene* sc, uint32_t* ext, uint32_t* sh, uint32_t n) {
+    int rc = check_scene(sc, "ptx_last_batch_counts");
+    if (rc) return rc;
+    if (!ext || !sh) return fail(PTX_E_ARG, "ptx_last_batch_counts: null argument");
+    const uint32_t B = sc->cap_bounces;
+    if (sc->pipes.empty() || B == 0) return fail(PTX_E_ARG, "ptx_last_batch_counts: nothing rendered yet");
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<uint32_t> host(4 * (size_t)B + 2);
+    HIP_TRY(hipMemcpy(host.data(), sc->pipes[sc->last_pipe]->counts.p, host.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (uint32_t b = 0; b < n; ++b) {
+        ext[b] = b < B ? host[b] : 0;
+        sh[b] = b < B ? host[B + 1 + b] : 0;
+    }
     return PTX_OK;
 }
 

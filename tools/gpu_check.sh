@@ -4,7 +4,7 @@ TAG=$1; shift
 timeout -k 10 400 python -u -m pytest tests/test_gpu_parity.py -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/t_$TAG.log 2>&1
 rc=$?; tail -3 gpurun_out/t_$TAG.log
 [ $rc -ne 0 ] && exit $rc
-timeout -k 10 300 python -u bench.py --steps 8 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err || { tail -5 gpurun_out/bench_$TAG.err; exit 1; }
+timeout -k 10 300 python -u bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err || { tail -5 gpurun_out/bench_$TAG.err; exit 1; }
 python3 - <<PY
 import json
 d=json.load(open('gpurun_out/bench_$TAG.json'))

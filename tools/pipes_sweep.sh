@@ -1,0 +1,10 @@
+#!/bin/bash
+for cfg in "2 24" "2 32" "3 16" "3 32" "2 48" "1 48" "1 96"; do
+  set -- $cfg
+  PTX_PIPES=$1 timeout -k 10 200 python -u bench.py --steps 4 --warmup 1 --spp-per-step 96 --batch-samples $2 --no-cpu-baseline > gpurun_out/p.json 2> gpurun_out/p.err || { echo "pipes=$1 batch=$2 FAILED"; tail -3 gpurun_out/p.err; continue; }
+  python3 - <<PY
+import json
+d=json.load(open('gpurun_out/p.json'))
+print('pipes=$1 batch=$2  samples/s %6.1fM extend %5.0f shadow %5.0f Mrays/s (per-kernel)  total rays/s %.2fG ms/step %6.2f'%(d['value']/1e6,d['extend_mrays_per_s'],d['shadow_mrays_per_s'],d['rays_per_s']/1e9,d['ms_per_step']))
+PY
+done
