@@ -159,7 +159,10 @@ __device__ inline void wave_add(unsigned long long* dst, uint32_t v) {
 #define PTX_REFILL_IDLE 16
 #endif
 #ifndef PTX_TRI_BATCH
-#define PTX_TRI_BATCH 1
+#define PTX_TRI_BATCH 24
+#endif
+#ifndef PTX_TRI_BATCH_ANY
+#define PTX_TRI_BATCH_ANY 16
 #endif
 #ifndef PTX_NT_STREAM
 #define PTX_NT_STREAM 0
@@ -171,7 +174,8 @@ constexpr int TBLOCK = PTX_TBLOCK;            // threads per traversal workgroup
 constexpr int LDS_DEPTH = PTX_LDS_DEPTH;      // stack levels kept in LDS
 constexpr int LDS_TOP_NODES = PTX_TOP_NODES;  // top-of-tree nodes cached in LDS (8 bytes each)
 constexpr uint32_t REFILL_IDLE = PTX_REFILL_IDLE;
-constexpr uint32_t TRI_BATCH = PTX_TRI_BATCH;
+constexpr uint32_t TRI_BATCH_NEAREST = PTX_TRI_BATCH;  // lanes that must wait in a leaf before the triangle step runs
+constexpr uint32_t TRI_BATCH_ANYHIT = PTX_TRI_BATCH_ANY;
 
 struct TravArgs {
     const uint2* nodes;  // device layout
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
             }
             const unsigned long long in_leaf = __ballot(have && tri_i < tri_n);
             const unsigned long long can_walk = __ballot(have && tri_i == tri_n && !leaf_end);
-            if (in_leaf && ((uint32_t)__popcll(in_leaf) >= TRI_BATCH || !can_walk)) {
+            if (in_leaf && ((uint32_t)__popcll(in_leaf) >= (ANY ? TRI_BATCH_ANYHIT : TRI_BATCH_NEAREST) || !can_walk)) {
                 if (have && tri_i < tri_n) {  // one triangle of the leaf: geometry/src/geometry.rs:176-196
                     const uint32_t idx = tri_n == 1u ? tri_off : a.leaf_idx[tri_off + tri_i];
                     if (COUNT) ++n_tris;
