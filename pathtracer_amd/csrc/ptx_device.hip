@@ -117,6 +117,34 @@ __device__ inline uint32_t block_slot(bool flag, uint32_t* counter, uint32_t* ld
     return slot;
 }
 
+// The same for two queues at once (one barrier sequence instead of two).
+__device__ inline void block_slot2(bool f0, bool f1, uint32_t* counter0, uint32_t* counter1,
+                                   uint32_t* lds /* 2 * WAVES + 2 */, uint32_t& slot0, uint32_t& slot1) {
+    const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t before0 = __popcll(b0 & lt), before1 = __popcll(b1 & lt);
+    if (lane == 0) {
+        lds[wave] = (uint32_t)__popcll(b0);
+        lds[WAVES + 1 + wave] = (uint32_t)__popcll(b1);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        uint32_t* l = lds + threadIdx.x * (WAVES + 1);
+        uint32_t total = 0;
+        for (int w = 0; w < WAVES; ++w) {
+            uint32_t c = l[w];
+            l[w] = total;
+            total += c;
+        }
+        l[WAVES] = total ? atomicAdd(threadIdx.x == 0 ? counter0 : counter1, total) : 0u;
+    }
+    __syncthreads();
+    slot0 = lds[WAVES] + lds[wave] + before0;
+    slot1 = lds[2 * WAVES + 1] + lds[WAVES + 1 + wave] + before1;
+    __syncthreads();  // lds is reused by the next iteration
+}
+
 __device__ inline void wave_add(unsigned long long* dst, uint32_t v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     if ((threadIdx.x & 63u) == 0 && v) atomicAdd(dst, (unsigned long long)v);
@@ -493,16 +521,18 @@ __device__ inline Bsdf material_sample(const DevMaterial& m, V3 wi, V3 n, float 
 }
 
 // One bounce of trace_ray (pathtracer.rs:33-108) for every entry of the current extend queue.
+template <int NL /* compile-time light count, 0 = read it from the scene */>
 __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, uint32_t bounce /* 1-based */) {
-    __shared__ uint32_t lds[WAVES + 1];
+    __shared__ uint32_t lds[2 * WAVES + 2];
     const uint32_t q = (bounce - 1u) & 1u;
     const ptx_ray* __restrict__ rays_in = st.rays[q];
     const uint32_t* __restrict__ pid_in = st.pids[q];
     ptx_ray* __restrict__ rays_out = st.rays[q ^ 1u];
     uint32_t* __restrict__ pid_out = st.pids[q ^ 1u];
     const uint32_t count = st.ext_counts[bounce - 1u];
-    const uint32_t n_lights = sc.n_lights;
+    const uint32_t n_lights = NL ? (uint32_t)NL : sc.n_lights;
     const uint32_t base = ptx_dim_base(bounce, n_lights);
+    constexpr int MAXL = NL ? NL : PTX_MAX_LIGHTS;
 
     for (uint32_t start = blockIdx.x * BLOCK; start < count; start += gridDim.x * BLOCK) {
         const uint32_t i = start + threadIdx.x;
@@ -510,7 +540,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, ui
         bool emit_next = false, emit_shadow = false;
         uint32_t pid = 0;
         V3 next_o = v3(0, 0, 0), next_d = v3(0, 0, 0), point_above = v3(0, 0, 0), T_old = v3(0, 0, 0);
-        V3 sh_dir[PTX_MAX_LIGHTS], sh_c[PTX_MAX_LIGHTS];
+        V3 sh_dir[MAXL], sh_c[MAXL];
         if (active) {
             pid = pid_in[i];
             const float4 ra = reinterpret_cast<const float4*>(rays_in)[2 * (size_t)i];
@@ -549,7 +579,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, ui
                 if (!smp.is_delta && n_lights > 0) {
                     emit_shadow = true;
                     T_old = T;
-                    for (uint32_t l = 0; l < n_lights; ++l) {
+#pragma unroll
+                    for (uint32_t l = 0; l < (NL ? (uint32_t)NL : n_lights); ++l) {
                         // Light::sample_shadow_ray (light.rs:34-37,69-76), uniform_sample_unit_sphere (sampling.rs:9-17)
                         const ptx_light& L = sc.lights[l];
                         const float z = ptx_sym_open(key, base + 3u + 2u * l);
@@ -582,23 +613,24 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, ui
                 }
             }
         }
-        const uint32_t slot_n = block_slot(emit_next, &st.ext_counts[bounce], lds);
+        // one compaction pass for both queues: wave ballots, LDS prefix over the waves, ONE atomic per
+        // workgroup and queue
+        uint32_t slot_n, slot_s;
+        block_slot2(emit_next, emit_shadow, &st.ext_counts[bounce], &st.sh_counts[bounce - 1u], lds, slot_n, slot_s);
         if (emit_next) {
             reinterpret_cast<float4*>(rays_out)[2 * (size_t)slot_n] = make_float4(next_o.x, next_o.y, next_o.z, 0.0f);
             reinterpret_cast<float4*>(rays_out)[2 * (size_t)slot_n + 1] =
                 make_float4(next_d.x, next_d.y, next_d.z, 3.402823466e+38f);
             pid_out[slot_n] = pid;
         }
-        if (n_lights > 0) {
-            const uint32_t slot_s = block_slot(emit_shadow, &st.sh_counts[bounce - 1u], lds);
-            if (emit_shadow) {
-                st.sh_T[slot_s] = make_float4(T_old.x, T_old.y, T_old.z, u2f(pid));
-                for (uint32_t l = 0; l < n_lights; ++l) {
-                    const size_t j = (size_t)slot_s * n_lights + l;
-                    reinterpret_cast<float4*>(st.sh_rays)[2 * j] = make_float4(point_above.x, point_above.y, point_above.z, 0.0f);
-                    reinterpret_cast<float4*>(st.sh_rays)[2 * j + 1] = make_float4(sh_dir[l].x, sh_dir[l].y, sh_dir[l].z, 1.0f);
-                    st.sh_contrib[j] = make_float4(sh_c[l].x, sh_c[l].y, sh_c[l].z, 0.0f);
-                }
+        if (emit_shadow) {
+            st.sh_T[slot_s] = make_float4(T_old.x, T_old.y, T_old.z, u2f(pid));
+#pragma unroll
+            for (uint32_t l = 0; l < (NL ? (uint32_t)NL : n_lights); ++l) {
+                const size_t j = (size_t)slot_s * n_lights + l;
+                reinterpret_cast<float4*>(st.sh_rays)[2 * j] = make_float4(point_above.x, point_above.y, point_above.z, 0.0f);
+                reinterpret_cast<float4*>(st.sh_rays)[2 * j + 1] = make_float4(sh_dir[l].x, sh_dir[l].y, sh_dir[l].z, 1.0f);
+                st.sh_contrib[j] = make_float4(sh_c[l].x, sh_c[l].y, sh_c[l].z, 0.0f);
             }
         }
     }
@@ -1194,7 +1226,10 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
             }
             {
                 Timed tm(sc, stream, KC_SHADE);
-                k_shade<<<grid, BLOCK, 0, stream>>>(sc->dev, st, b);
+                if (L == 1) k_shade<1><<<grid, BLOCK, 0, stream>>>(sc->dev, st, b);
+                else if (L == 2) k_shade<2><<<grid, BLOCK, 0, stream>>>(sc->dev, st, b);
+                else if (L == 4) k_shade<4><<<grid, BLOCK, 0, stream>>>(sc->dev, st, b);
+                else k_shade<0><<<grid, BLOCK, 0, stream>>>(sc->dev, st, b);
             }
             if (L > 0) {
                 Timed tm(sc, stream, KC_SHADOW);
