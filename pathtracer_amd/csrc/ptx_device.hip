@@ -579,7 +579,6 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, ui
                 if (!smp.is_delta && n_lights > 0) {
                     emit_shadow = true;
                     T_old = T;
-#pragma unroll
                     for (uint32_t l = 0; l < (NL ? (uint32_t)NL : n_lights); ++l) {
                         // Light::sample_shadow_ray (light.rs:34-37,69-76), uniform_sample_unit_sphere (sampling.rs:9-17)
                         const ptx_light& L = sc.lights[l];
@@ -625,7 +624,6 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, ui
         }
         if (emit_shadow) {
             st.sh_T[slot_s] = make_float4(T_old.x, T_old.y, T_old.z, u2f(pid));
-#pragma unroll
             for (uint32_t l = 0; l < (NL ? (uint32_t)NL : n_lights); ++l) {
                 const size_t j = (size_t)slot_s * n_lights + l;
                 reinterpret_cast<float4*>(st.sh_rays)[2 * j] = make_float4(point_above.x, point_above.y, point_above.z, 0.0f);
@@ -1161,17 +1159,24 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
     if (n_pixels64 > (1ull << 27)) return fail(PTX_E_LIMIT, "ptx_render: image larger than 2^27 pixels");
     if ((uint64_t)first_sample + sample_count > 0xFFFFFFFFull) return fail(PTX_E_LIMIT, "ptx_render: sample index overflow");
     const uint32_t n_pixels = (uint32_t)n_pixels64;
+    // Batch size: large batches amortise the long-ray tail of every launch (measured at 1080^2: 5 -> 64
+    // samples per batch raises the traversal kernels from 2.5 to ~7 Grays/s), and the batches of one call
+    // are spread evenly over the pipelines so that all of them run concurrently.  ~230 B of queue state
+    // per path: the default budget of 160 Mi paths in flight is ~37 GB of the 288 GB of HBM.
+    const uint32_t n_pipes = sc->n_pipes;
     uint32_t S = sc->batch_samples;
     if (S == 0) {
-        // large batches amortise the long-ray tail of every launch (measured: 5 -> 48 samples in flight at
-        // 1080^2 raises the traversal kernels from 2.5 to 5.5 Grays/s); ~200 B of queue state per path
-        S = (uint32_t)((48u << 20) / n_pixels);
-        if (S < 1) S = 1;
-        if (S > 64) S = 64;
+        const uint64_t budget = (160ull << 20) / ((uint64_t)n_pipes * n_pixels);
+        S = (uint32_t)(budget < 1 ? 1 : (budget > 256 ? 256 : budget));
+        const uint32_t per_pipe = (sample_count + n_pipes - 1) / n_pipes;
+        if (per_pipe > 0 && per_pipe < S) S = per_pipe;
     }
     while ((uint64_t)S * n_pixels > (1ull << 28)) S = (S + 1) / 2;  // path ids are 32-bit; keep slots < 2^28
-    if (sample_count > 0) {  // equal-sized batches: ceil(count / ceil(count / S))
-        const uint32_t n_batches = (sample_count + S - 1) / S;
+    if (S < 1) S = 1;
+    if (sample_count > 0) {  // equal-sized batches, their number a multiple of the pipeline count when possible
+        uint32_t n_batches = (sample_count + S - 1) / S;
+        if (sc->batch_samples == 0 && n_batches > 1) n_batches = (n_batches + n_pipes - 1) / n_pipes * n_pipes;
+        if (n_batches > sample_count) n_batches = sample_count;
         S = (sample_count + n_batches - 1) / n_batches;
     }
     int rc = ensure_render_state(sc, (size_t)S * n_pixels);

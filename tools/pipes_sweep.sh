@@ -1,7 +1,7 @@
 #!/bin/bash
-for cfg in "2 24" "2 32" "3 16" "3 32" "2 48" "1 48" "1 96"; do
+for cfg in "2 0" "3 0" "4 0"; do
   set -- $cfg
-  PTX_PIPES=$1 timeout -k 10 200 python -u bench.py --steps 4 --warmup 1 --spp-per-step 96 --batch-samples $2 --no-cpu-baseline > gpurun_out/p.json 2> gpurun_out/p.err || { echo "pipes=$1 batch=$2 FAILED"; tail -3 gpurun_out/p.err; continue; }
+  PTX_PIPES=$1 timeout -k 10 200 python -u bench.py --steps 3 --warmup 1 --batch-samples $2 --no-cpu-baseline > gpurun_out/p.json 2> gpurun_out/p.err || { echo "pipes=$1 batch=$2 FAILED"; tail -3 gpurun_out/p.err; continue; }
   python3 - <<PY
 import json
 d=json.load(open('gpurun_out/p.json'))
