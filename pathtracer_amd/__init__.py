@@ -354,6 +354,13 @@ class DeviceScene:
     def stats_reset(self):
         _check(lib().ptx_stats_reset(self._h))
 
+    def loop_profile(self):
+        """Diagnostic (FLAG_COUNT_WORK scenes): lane occupancy of the traversal loop, per kernel."""
+        raw = np.zeros(16, np.uint64)
+        _check(lib().ptx_debug_loop_profile(self._h, _ptr(raw)))
+        keys = ("iters", "walk_lanes", "tri_iters", "tri_lanes", "end_iters", "end_lanes", "refills", "live_lanes")
+        return {"extend": dict(zip(keys, (int(x) for x in raw[:8]))), "shadow": dict(zip(keys, (int(x) for x in raw[8:])))}
+
 
 def to_rgb8(accum, iterations):
     """`ImageBuffer::to_rgb8(iterations as u16)`."""

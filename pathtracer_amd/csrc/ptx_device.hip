@@ -219,6 +219,7 @@ struct TravArgs {
     uint2* spill;      // [(PTX_MAX_DEPTH - LDS_DEPTH) * spill_stride]
     uint32_t spill_stride;
     unsigned long long* work;  // [2] inner nodes, triangle tests (COUNT)
+    unsigned long long* prof;  // [8] loop profile (COUNT): see ptx_debug_loop_profile
 };
 
 template <bool ANY, bool COUNT>
@@ -245,8 +246,10 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
     uint32_t bi = PTX_MISS;
     float bt = 0.0f, bu = 0.0f, bv = 0.0f;
     uint32_t n_inner = 0, n_tris = 0;
+    uint32_t pf_iter = 0, pf_walk = 0, pf_tri_iter = 0, pf_tri = 0, pf_end_iter = 0, pf_end = 0, pf_refill = 0, pf_live = 0;
 
     for (;;) {
+        if (COUNT) pf_refill += lane == 0 ? 1u : 0u;
         // ---- refill idle lanes from the wave's window
         for (;;) {
             const unsigned long long idle = __ballot(!have);
@@ -291,6 +294,7 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
         for (;;) {
             bool leaf_end = false;
             const bool walking = have && tri_i == tri_n;
+            if (COUNT) pf_iter += lane == 0 ? 1u : 0u, pf_walk += walking ? 1u : 0u, pf_live += have ? 1u : 0u;
             if (walking) {  // node visit, kdtree/src/lib.rs:105-129, written with selects instead of branches
 #if PTX_TOP_NODES > 0
                 uint2 nd;
@@ -333,7 +337,9 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
             const unsigned long long in_leaf = __ballot(have && tri_i < tri_n);
             const unsigned long long can_walk = __ballot(have && tri_i == tri_n && !leaf_end);
             if (in_leaf && ((uint32_t)__popcll(in_leaf) >= (ANY ? TRI_BATCH_ANYHIT : TRI_BATCH_NEAREST) || !can_walk)) {
+                if (COUNT) pf_tri_iter += lane == 0 ? 1u : 0u;
                 if (have && tri_i < tri_n) {  // one triangle of the leaf: geometry/src/geometry.rs:176-196
+                    if (COUNT) ++pf_tri;
                     const uint32_t idx = tri_n == 1u ? tri_off : a.leaf_idx[tri_off + tri_i];
                     if (COUNT) ++n_tris;
                     ++tri_i;
@@ -347,7 +353,9 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                     leaf_end = tri_i == tri_n;
                 }
             }
+            if (COUNT && __any(leaf_end)) pf_end_iter += lane == 0 ? 1u : 0u;
             if (leaf_end) {  // kdtree/src/lib.rs:95-103
+                if (COUNT) ++pf_end;
                 tri_i = tri_n = 0;
                 bool done = bi != PTX_MISS;
                 if (!done) {
@@ -391,6 +399,14 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
     if (COUNT) {
         wave_add(&a.work[0], n_inner);
         wave_add(&a.work[1], n_tris);
+        wave_add(&a.prof[0], pf_iter);
+        wave_add(&a.prof[1], pf_walk);
+        wave_add(&a.prof[2], pf_tri_iter);
+        wave_add(&a.prof[3], pf_tri);
+        wave_add(&a.prof[4], pf_end_iter);
+        wave_add(&a.prof[5], pf_end);
+        wave_add(&a.prof[6], pf_refill);
+        wave_add(&a.prof[7], pf_live);
     }
 }
 
@@ -881,8 +897,8 @@ int ensure_render_state(ptx_scene* sc, size_t paths) {
         HIP_TRY(p.counts.ensure(4 * (size_t)B + 2));
     }
     if (!sc->totals.p) {
-        HIP_TRY(sc->totals.ensure(8));
-        HIP_TRY(hipMemset(sc->totals.p, 0, 8 * sizeof(unsigned long long)));
+        HIP_TRY(sc->totals.ensure(24));
+        HIP_TRY(hipMemset(sc->totals.p, 0, 24 * sizeof(unsigned long long)));
     }
     sc->cap_paths = paths > sc->cap_paths ? paths : sc->cap_paths;
     sc->cap_lights = L > sc->cap_lights ? L : sc->cap_lights;
@@ -974,6 +990,7 @@ int launch_traverse(ptx_scene* sc, const ptx_ray* d_rays, const uint32_t* d_coun
     a.spill = d_spill;
     a.spill_stride = (uint32_t)sc->tgrid * TBLOCK;
     a.work = work;
+    a.prof = sc->totals.p + (ANY ? 16 : 8);
     int grid = sc->tgrid;  // the spill area is sized for this many threads: never launch more
     if (!d_count) {
         int need = (int)((n + 63) / 64 + (TBLOCK / 64) - 1) / (TBLOCK / 64);
@@ -1082,8 +1099,8 @@ int ptx_scene_create(const ptx_scene_desc* d, uint32_t flags, ptx_scene** out) {
     for (uint32_t l = 0; l < d->n_lights; ++l) sc->dev.lights[l] = d->lights[l];
     memcpy(sc->dev.env, d->environment, sizeof sc->dev.env);
     sc->dev.max_bounces = d->max_bounces;
-    HIP_TRY(sc->totals.ensure(8));
-    HIP_TRY(hipMemset(sc->totals.p, 0, 8 * sizeof(unsigned long long)));
+    HIP_TRY(sc->totals.ensure(24));
+    HIP_TRY(hipMemset(sc->totals.p, 0, 24 * sizeof(unsigned long long)));
     HIP_TRY(sc->spill.ensure((size_t)(PTX_MAX_DEPTH - LDS_DEPTH) * sc->tgrid * TBLOCK));
     HIP_TRY(sc->batch_cursor.ensure(1));
     *out = sc.release();
@@ -1337,12 +1354,22 @@ int ptx_stats(ptx_scene* sc, ptx_counters* out) {
     return PTX_OK;
 }
 
+int ptx_debug_loop_profile(ptx_scene* sc, uint64_t* out16) {
+    int rc = check_scene(sc, "ptx_debug_loop_profile");
+    if (rc) return rc;
+    if (!out16) return fail(PTX_E_ARG, "ptx_debug_loop_profile: null argument");
+    HIP_TRY(hipDeviceSynchronize());
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "");
+    HIP_TRY(hipMemcpy(out16, sc->totals.p + 8, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return PTX_OK;
+}
+
 int ptx_stats_reset(ptx_scene* sc) {
     int rc = check_scene(sc, "ptx_stats_reset");
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     resolve_stamps(sc);
-    HIP_TRY(hipMemset(sc->totals.p, 0, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(sc->totals.p, 0, 24 * sizeof(unsigned long long)));
     for (double& v : sc->class_ms) v = 0;
     sc->total_ms = 0;
     sc->samples_done = 0;

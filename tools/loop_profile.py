@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Lane occupancy of the traversal loop on the bench workload (counting variant of the kernels)."""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import pathtracer_amd as pt
+
+scene_name = sys.argv[1] if len(sys.argv) > 1 else "cornell_teapot"
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+W = H = 1080
+scene = pt.LoadedScene(os.path.join(os.path.dirname(__file__), "..", "scenes", scene_name + ".obj"), max_bounces=10)
+dev = scene.upload(flags=pt.FLAG_COUNT_WORK)
+acc = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
+dev.render_device(scene.pinhole(W, H), spp, acc.data_ptr(), seed=0, first_sample=0, stream=torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+st = dev.stats()
+pf = dev.loop_profile()
+for k, rays, inner, tris in (("extend", st["extend_rays"], st["extend_inner_nodes"], st["extend_tri_tests"]),
+                            ("shadow", st["shadow_rays"], st["shadow_inner_nodes"], st["shadow_tri_tests"])):
+    p = pf[k]
+    it = max(p["iters"], 1)
+    print("%s: rays %d  inner/ray %.2f  tris/ray %.2f  leaf-exits/ray %.2f" % (k, rays, inner / rays, tris / rays, p["end_lanes"] / rays))
+    print("   wave iterations/ray*64 = %.1f  (node-step visits/ray %.2f)" % (it * 64 / rays, p["walk_lanes"] / rays))
+    print("   node step: lanes active %.1f/64   live lanes %.1f/64" % (p["walk_lanes"] / it, p["live_lanes"] / it))
+    print("   tri step : ran in %.1f%% of iterations, lanes active %.1f/64" % (100 * p["tri_iters"] / it, p["tri_lanes"] / max(p["tri_iters"], 1)))
+    print("   leaf exit: ran in %.1f%% of iterations, lanes active %.1f/64" % (100 * p["end_iters"] / it, p["end_lanes"] / max(p["end_iters"], 1)))
+    print("   refill rounds per 100 iterations %.1f" % (100 * p["refills"] / it))
