@@ -25,6 +25,7 @@ std::string validate_flat_tree(const ptx_kdnode* nodes, uint32_t n_nodes, const 
 //   kind 3 (general, Möller–Trumbore):  f[0..2]=v0  f[3..5]=e1=v1-v0  f[6..8]=e2=v2-v0
 //   kind 0/1/2 (axis-aligned on X/Y/Z): f[0]=plane distance  f[1..2]=v0'  f[3..4]=b1=v1'-v0'
 //                                        f[5..6]=b2=v2'-v0'  (' = the two remaining coordinates)
+//                                        f[7]=1/det(b1,b2), NaN when det == 0
 using TriRecord = TriRec;
 void pack_triangles(const float* tris, uint32_t n, std::vector<TriRecord>& out);
 

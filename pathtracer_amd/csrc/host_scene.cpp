@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <limits>
 #include <map>
 #include <memory>
 #include <sstream>
@@ -528,6 +529,8 @@ void pack_triangles(const float* t, uint32_t n, std::vector<TriRecord>& out) {
             r.f[4] = v[3 + a1] - v[a1];
             r.f[5] = v[6 + a0] - v[a0];
             r.f[6] = v[6 + a1] - v[a1];
+            const float det = r.f[3] * r.f[6] - r.f[5] * r.f[4];  // axial_triangle.rs:70
+            r.f[7] = det == 0.0f ? std::numeric_limits<float>::quiet_NaN() : 1.0f / det;
         }
     }
 }

@@ -151,26 +151,30 @@ __device__ inline void wave_add(unsigned long long* dst, uint32_t v) {
 }
 
 // ------------------------------------------------------------------------------------------ kernels
-// Persistent traversal with lane refill over a device-private node layout.
+// Persistent traversal with lane refill over a device-private tree of child descriptors.
 //
-// Device node layout (built by relayout_nodes() from the ABI's preorder array; same tree, same 8 bytes):
-//   inner: x = bits of plane distance, y = (index of LEFT child << 2) | axis; the right child is left + 1
-//   leaf : x = offset into the leaf index list (or the triangle index itself when the leaf holds exactly
-//          one triangle), y = (count << 2) | 3
-//   Nodes of depth <= top_depth come first, in breadth-first order, so that nodes [0, top_count) are the
-//   top of the tree: every workgroup copies them into LDS once and serves ~60 % of all node visits
-//   (measured on cornell_teapot / sr2 ray sets) without touching the vector memory path.  Deeper nodes
-//   follow in depth-first order (siblings adjacent) for L1/L2 locality.
+// Device tree (built by build_device_tree() from the ABI's preorder array; same tree, same decisions):
+//   only INNER nodes are stored, 16 bytes each (one dwordx4 load per visit):
+//       x = bits of the plane distance, y = axis, z = descriptor of the LEFT child, w = of the RIGHT child
+//   a descriptor (int32) says what a child is without visiting it:
+//       >= 0              index of an inner node
+//       0x80000000 | off  leaf with two or more triangles: dev_leaf[off ..] holds their indices, bit 31
+//                         set on the last one
+//       0xC0000000 | idx  leaf with exactly one triangle (the index is inline)
+//       DESC_EXIT  (-1)   empty leaf, which is the same thing as "this lane must leave its leaf"
+//       DESC_IDLE  (-2)   the lane holds no ray
+//   so a lane's whole control state is ONE register (`cur`), every predicate of the loop is one compare,
+//   and arriving at a leaf costs no node visit (19 % of the visits of the 8-byte layout on cornell_teapot).
+//   Inner nodes are numbered depth-first with siblings adjacent.
 //
 // Scheduling
 //   * every wave owns a cursor window [lo,hi) of the ray array, taken `chunk` rays at a time with ONE
 //     atomic on the launch's cursor; lanes whose ray has finished are refilled from the window as soon
 //     as REFILL_IDLE lanes of the wave are idle, so a long ray never holds 63 idle lanes hostage;
-//   * a live lane is either walking nodes or standing in a leaf with triangles left to test.  Each
-//     loop iteration steps all node-walking lanes by one node; the triangle step (4 vector loads) only
-//     runs when at least TRI_BATCH lanes are waiting for it or no lane can walk any further, so its
-//     loads are issued for many lanes at once;
-//   * the traversal stack (far child, t_split) lives in LDS for the first LDS_DEPTH levels
+//   * each loop iteration steps all node-walking lanes by one node; the triangle step (one index load,
+//     three 16-byte loads) only runs when at least TRI_BATCH lanes are waiting for it or no lane can
+//     walk any further; lanes that have left their leaf pop or finish in the same iteration;
+//   * the traversal stack (far child descriptor, t_split) lives in LDS for the first LDS_DEPTH levels
 //     ([level][thread]: ds_write_b64 / ds_read_b64 without bank conflicts) and in a per-thread global
 //     spill area beyond that (the reference allows 25 levels, kdtree/src/lib.rs:16).
 // Decisions per ray are exactly those of kd_traverse() in traverse.hpp (= KdNode::intersect).
@@ -179,9 +183,6 @@ __device__ inline void wave_add(unsigned long long* dst, uint32_t v) {
 #endif
 #ifndef PTX_LDS_DEPTH
 #define PTX_LDS_DEPTH 8
-#endif
-#ifndef PTX_TOP_NODES
-#define PTX_TOP_NODES 0
 #endif
 #ifndef PTX_REFILL_IDLE
 #define PTX_REFILL_IDLE 16
@@ -192,27 +193,27 @@ __device__ inline void wave_add(unsigned long long* dst, uint32_t v) {
 #ifndef PTX_TRI_BATCH_ANY
 #define PTX_TRI_BATCH_ANY 16
 #endif
-#ifndef PTX_NT_STREAM
-#define PTX_NT_STREAM 0
-#endif
 #ifndef PTX_BLOCKS_PER_CU
 #define PTX_BLOCKS_PER_CU 4
 #endif
-constexpr int TBLOCK = PTX_TBLOCK;            // threads per traversal workgroup
-constexpr int LDS_DEPTH = PTX_LDS_DEPTH;      // stack levels kept in LDS
-constexpr int LDS_TOP_NODES = PTX_TOP_NODES;  // top-of-tree nodes cached in LDS (8 bytes each)
+constexpr int TBLOCK = PTX_TBLOCK;        // threads per traversal workgroup
+constexpr int LDS_DEPTH = PTX_LDS_DEPTH;  // stack levels kept in LDS
 constexpr uint32_t REFILL_IDLE = PTX_REFILL_IDLE;
 constexpr uint32_t TRI_BATCH_NEAREST = PTX_TRI_BATCH;  // lanes that must wait in a leaf before the triangle step runs
 constexpr uint32_t TRI_BATCH_ANYHIT = PTX_TRI_BATCH_ANY;
 
+constexpr int32_t DESC_EXIT = -1, DESC_IDLE = -2;
+constexpr uint32_t DESC_MULTI = 0x80000000u, DESC_SINGLE = 0xC0000000u, DESC_PAYLOAD = 0x3FFFFFFFu;
+constexpr uint32_t DESC_MAX_PAYLOAD = 0x3FFFFFFDu;  // keeps DESC_SINGLE | idx clear of the two specials
+
 struct TravArgs {
-    const uint2* nodes;  // device layout
-    uint32_t top_count;  // nodes [0, top_count) are cached in LDS
-    const uint32_t* leaf_idx;
+    const uint4* nodes;        // inner nodes, device layout
+    const uint32_t* leaf_list; // triangle indices of the multi-triangle leaves, last one flagged
     const TriRec* tris;
     const ptx_ray* rays;
     const uint32_t* count_ptr;  // device-side ray count (x count_scale), or NULL to use fixed_count
     uint32_t count_scale, fixed_count;
+    int32_t root;    // descriptor of the root
     ptx_hit* hits;   // nearest-hit output (ANY == false)
     uint8_t* occ;    // occlusion output    (ANY == true)
     uint32_t* cursor;  // zero before the launch
@@ -225,24 +226,19 @@ struct TravArgs {
 template <bool ANY, bool COUNT>
 __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
     __shared__ uint2 s_stack[LDS_DEPTH][TBLOCK];
-    __shared__ uint2 s_top[LDS_TOP_NODES > 0 ? LDS_TOP_NODES : 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t gtid = blockIdx.x * TBLOCK + tid;
     const uint32_t count = a.count_ptr ? *a.count_ptr * a.count_scale : a.fixed_count;
-    const uint32_t top_count = a.top_count;
-    for (uint32_t i = tid; i < top_count; i += TBLOCK) s_top[i] = a.nodes[i];
-    __syncthreads();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     // window size: ~4 windows per wave over the launch, 64..512 rays, multiple of 64
     uint32_t chunk = count / (gridDim.x * (TBLOCK / 64) * 4u);
     chunk = chunk < 64u ? 64u : (chunk > 512u ? 512u : (chunk & ~63u));
     uint32_t lo = 0, hi = 0;
     bool drained = false;  // the launch's cursor has passed `count`
-    bool have = false;
+    int32_t cur = DESC_IDLE;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, t_end = 0, t1 = 0, t2 = 0;
-    uint32_t node = 0, ridx = 0;
+    uint32_t ridx = 0;
     int sp = 0;
-    uint32_t tri_off = 0, tri_n = 0, tri_i = 0;  // tri_i < tri_n: standing in a leaf with triangles left
     uint32_t bi = PTX_MISS;
     float bt = 0.0f, bu = 0.0f, bv = 0.0f;
     uint32_t n_inner = 0, n_tris = 0;
@@ -252,7 +248,7 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
         if (COUNT) pf_refill += lane == 0 ? 1u : 0u;
         // ---- refill idle lanes from the wave's window
         for (;;) {
-            const unsigned long long idle = __ballot(!have);
+            const unsigned long long idle = __ballot(cur == DESC_IDLE);
             if (!idle) break;
             if (lo >= hi) {
                 if (drained) break;
@@ -269,129 +265,104 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
             const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             const uint32_t avail = hi - lo;
-            if (!have && rank < avail) {
+            if (cur == DESC_IDLE && rank < avail) {
                 ridx = lo + rank;
-#if PTX_NT_STREAM
-                const float4 ra = __builtin_nontemporal_load(reinterpret_cast<const float4*>(a.rays) + 2 * (size_t)ridx);
-                const float4 rb = __builtin_nontemporal_load(reinterpret_cast<const float4*>(a.rays) + 2 * (size_t)ridx + 1);
-#else
                 const float4 ra = reinterpret_cast<const float4*>(a.rays)[2 * (size_t)ridx];
                 const float4 rb = reinterpret_cast<const float4*>(a.rays)[2 * (size_t)ridx + 1];
-#endif
                 ox = ra.x, oy = ra.y, oz = ra.z, t1 = ra.w;
                 dx = rb.x, dy = rb.y, dz = rb.z, t2 = t_end = rb.w;
-                node = 0;
+                cur = a.root;
                 sp = 0;
-                tri_i = tri_n = 0;
                 bi = PTX_MISS;
-                have = true;
             }
             lo += n_idle < avail ? n_idle : avail;
         }
-        if (!__any(have)) break;
+        if (__ballot(cur != DESC_IDLE) == 0ull) break;
 
         // ---- step the live lanes until enough of them have finished to make a refill worthwhile
         for (;;) {
-            bool leaf_end = false;
-            const bool walking = have && tri_i == tri_n;
-            if (COUNT) pf_iter += lane == 0 ? 1u : 0u, pf_walk += walking ? 1u : 0u, pf_live += have ? 1u : 0u;
-            if (walking) {  // node visit, kdtree/src/lib.rs:105-129, written with selects instead of branches
-#if PTX_TOP_NODES > 0
-                uint2 nd;
-                if (node < top_count) nd = s_top[node];
-                else nd = a.nodes[node];
-#else
-                const uint2 nd = a.nodes[node];
-#endif
-                const uint32_t kind = nd.y & 3u;
-                const bool is_leaf = kind == 3u;
-                if (COUNT) n_inner += is_leaf ? 0u : 1u;
+            if (COUNT) pf_iter += lane == 0 ? 1u : 0u, pf_walk += cur >= 0 ? 1u : 0u, pf_live += cur != DESC_IDLE ? 1u : 0u;
+            if (cur >= 0) {  // node visit, kdtree/src/lib.rs:105-129
+                const uint4 nd = a.nodes[cur];
+                if (COUNT) ++n_inner;
+                const uint32_t axis = nd.y;
                 const float dist = u2f(nd.x);
-                const float da = pick(dx, dy, dz, kind);
-                const float oa = pick(ox, oy, oz, kind);
-                const uint32_t left = nd.y >> 2, right = left + 1u;
-                const float t = (dist - oa) / da;  // unused (selected away) when da == 0 or on a leaf
+                const float da = pick(dx, dy, dz, axis);
+                const float oa = pick(ox, oy, oz, axis);
+                const float t = (dist - oa) / da;  // unused (selected away) when da == 0
                 const bool fwd = da >= 0.0f;
-                const uint32_t near_n = fwd ? left : right;
-                const uint32_t far_n = fwd ? right : left;
+                const uint32_t near_d = fwd ? nd.z : nd.w;
+                const uint32_t far_d = fwd ? nd.w : nd.z;
                 const bool parallel = da == 0.0f;
                 const bool only_near = t > t2, only_far = t < t1;
-                const bool push = !is_leaf && !parallel && !only_near && !only_far;
-                uint32_t next = only_far ? far_n : near_n;
-                next = parallel ? (oa <= dist ? left : right) : next;
+                const bool push = !parallel && !only_near && !only_far;
+                uint32_t next = only_far ? far_d : near_d;
+                next = parallel ? (oa <= dist ? nd.z : nd.w) : next;
                 if (push) {
-                    const uint2 e = make_uint2(far_n, f2u(t));
+                    const uint2 e = make_uint2(far_d, f2u(t));
                     if (sp < LDS_DEPTH) s_stack[sp][tid] = e;
                     else a.spill[(size_t)(sp - LDS_DEPTH) * a.spill_stride + gtid] = e;
+                    ++sp;
+                    t2 = t;
                 }
-                sp += push ? 1 : 0;
-                t2 = push ? t : t2;
-                node = is_leaf ? node : next;
-                // leaf entry (kdtree/src/lib.rs:88-94); an empty leaf is resolved at once
-                tri_n = is_leaf ? nd.y >> 2 : tri_n;
-                tri_off = is_leaf ? nd.x : tri_off;
-                tri_i = is_leaf ? 0u : tri_i;
-                bi = is_leaf ? PTX_MISS : bi;
-                leaf_end = is_leaf && (nd.y >> 2) == 0u;
+                cur = (int32_t)next;
             }
-            const unsigned long long in_leaf = __ballot(have && tri_i < tri_n);
-            const unsigned long long can_walk = __ballot(have && tri_i == tri_n && !leaf_end);
+            const unsigned long long in_leaf = __ballot(cur < -2);
+            const unsigned long long can_walk = __ballot(cur >= 0);
             if (in_leaf && ((uint32_t)__popcll(in_leaf) >= (ANY ? TRI_BATCH_ANYHIT : TRI_BATCH_NEAREST) || !can_walk)) {
                 if (COUNT) pf_tri_iter += lane == 0 ? 1u : 0u;
-                if (have && tri_i < tri_n) {  // one triangle of the leaf: geometry/src/geometry.rs:176-196
-                    if (COUNT) ++pf_tri;
-                    const uint32_t idx = tri_n == 1u ? tri_off : a.leaf_idx[tri_off + tri_i];
-                    if (COUNT) ++n_tris;
-                    ++tri_i;
+                if (cur < -2) {  // one triangle of the leaf: geometry/src/geometry.rs:176-196
+                    if (COUNT) ++pf_tri, ++n_tris;
+                    uint32_t e = (uint32_t)cur;
+                    if (e < DESC_SINGLE) e = a.leaf_list[e & DESC_PAYLOAD];
+                    const uint32_t idx = e & DESC_PAYLOAD;
+                    const bool last = (int32_t)e < 0;
+                    TriRec rec;  // the whole 48-byte record in one go; the kind is its last word
+                    {
+                        const float4* rp = reinterpret_cast<const float4*>(a.tris + idx);
+                        const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+                        __builtin_memcpy(&rec.f[0], &r0, 16);
+                        __builtin_memcpy(&rec.f[4], &r1, 16);
+                        __builtin_memcpy(&rec.f[8], &r2, 16);
+                    }
                     float t, u, v;
-                    if (tri_test(a.tris[idx], ox, oy, oz, dx, dy, dz, t, u, v) && t1 <= t && t <= t2) {
+                    bool accept = false;
+                    if (tri_test(rec, ox, oy, oz, dx, dy, dz, t, u, v) && t1 <= t && t <= t2) {
                         if (bi == PTX_MISS || !(bt <= t)) {  // the earlier triangle wins t ties
                             bt = t, bu = u, bv = v, bi = idx;
-                            if (ANY) tri_i = tri_n;
+                            accept = true;
                         }
                     }
-                    leaf_end = tri_i == tri_n;
+                    cur = (last || (ANY && accept)) ? DESC_EXIT : cur + 1;
                 }
             }
-            if (COUNT && __any(leaf_end)) pf_end_iter += lane == 0 ? 1u : 0u;
-            if (leaf_end) {  // kdtree/src/lib.rs:95-103
+            if (COUNT && __any(cur == DESC_EXIT)) pf_end_iter += lane == 0 ? 1u : 0u;
+            if (cur == DESC_EXIT) {  // leaving a leaf: kdtree/src/lib.rs:95-103
                 if (COUNT) ++pf_end;
-                tri_i = tri_n = 0;
-                bool done = bi != PTX_MISS;
-                if (!done) {
-                    if (t2 == t_end || sp == 0) {
-                        done = true;
-                    } else {
-                        --sp;
-                        const uint2 e = sp < LDS_DEPTH ? s_stack[sp][tid]
-                                                       : a.spill[(size_t)(sp - LDS_DEPTH) * a.spill_stride + gtid];
-                        node = e.x;
-                        t1 = u2f(e.y);
-                        if (sp == 0) {
-                            t2 = t_end;
-                        } else {
-                            const uint2 below = sp - 1 < LDS_DEPTH
-                                                    ? s_stack[sp - 1][tid]
-                                                    : a.spill[(size_t)(sp - 1 - LDS_DEPTH) * a.spill_stride + gtid];
-                            t2 = u2f(below.y);
-                        }
-                    }
-                }
-                if (done) {
+                if (bi != PTX_MISS || t2 == t_end || sp == 0) {
                     if (ANY) {
                         a.occ[ridx] = bi != PTX_MISS ? 1 : 0;
                     } else {
                         const uint4 hv = bi != PTX_MISS ? make_uint4(bi, f2u(bt), f2u(bu), f2u(bv)) : make_uint4(PTX_MISS, 0u, 0u, 0u);
-#if PTX_NT_STREAM
-                        __builtin_nontemporal_store(hv, reinterpret_cast<uint4*>(a.hits) + ridx);
-#else
                         reinterpret_cast<uint4*>(a.hits)[ridx] = hv;
-#endif
                     }
-                    have = false;
+                    cur = DESC_IDLE;
+                } else {
+                    --sp;
+                    // the LDS reads are unconditional (clamped level), the spill reads a rare branch on top
+                    const int below = sp > 0 ? sp - 1 : 0;
+                    uint2 e = s_stack[sp < LDS_DEPTH ? sp : LDS_DEPTH - 1][tid];
+                    uint32_t tb = s_stack[below < LDS_DEPTH ? below : LDS_DEPTH - 1][tid].y;
+                    if (sp >= LDS_DEPTH) {
+                        e = a.spill[(size_t)(sp - LDS_DEPTH) * a.spill_stride + gtid];
+                        if (below >= LDS_DEPTH) tb = a.spill[(size_t)(below - LDS_DEPTH) * a.spill_stride + gtid].y;
+                    }
+                    cur = (int32_t)e.x;
+                    t1 = u2f(e.y);
+                    t2 = sp > 0 ? u2f(tb) : t_end;
                 }
             }
-            const uint32_t live = (uint32_t)__popcll(__ballot(have));
+            const uint32_t live = (uint32_t)__popcll(__ballot(cur != DESC_IDLE));
             if (live == 0) break;
             if (!(drained && lo >= hi) && live <= 64u - REFILL_IDLE) break;
         }
@@ -749,8 +720,9 @@ struct ptx_scene {
     uint32_t n_triangles = 0, n_nodes = 0;
     bool shading = false;
     DevBuf<ptx_kdnode> nodes;
-    DevBuf<uint2> dev_nodes;  // traversal layout (see k_traverse)
-    uint32_t top_count = 0;
+    DevBuf<uint4> dev_nodes;     // traversal layout (see k_traverse)
+    DevBuf<uint32_t> dev_leaf;  // triangle lists of the multi-triangle leaves, last entry flagged
+    int32_t root_desc = DESC_EXIT;
     int tgrid = 1024;  // traversal workgroups (TBLOCK threads each)
     DevBuf<uint32_t> leaf_idx;
     DevBuf<TriRec> tris;
@@ -913,61 +885,55 @@ int check_scene(ptx_scene* sc, const char* who) {
     return PTX_OK;
 }
 
-// Re-index the ABI's preorder tree into the device layout described above k_traverse.
-void relayout_nodes(const ptx_kdnode* in, uint32_t n_nodes, const uint32_t* leaf_idx, std::vector<uint2>& out,
-                    uint32_t& top_count) {
-    out.assign(n_nodes, make_uint2(0u, 3u));
+// Re-index the ABI's preorder tree into the device layout described above k_traverse.  Returns an empty
+// string, or why the tree does not fit the descriptor fields.
+std::string build_device_tree(const ptx_kdnode* in, uint32_t n_nodes, const uint32_t* leaf_idx, std::vector<uint4>& nodes,
+                              std::vector<uint32_t>& list, int32_t& root) {
     auto is_leaf = [&](uint32_t i) { return (in[i].w1 & 3u) == 3u; };
-    auto emit = [&](uint32_t src, uint32_t dst, uint32_t left_dst) {
-        if (is_leaf(src)) {
-            const uint32_t cnt = in[src].w1 >> 2;
-            out[dst] = make_uint2(cnt == 1u ? leaf_idx[in[src].w0] : in[src].w0, in[src].w1);
-        } else {
-            out[dst] = make_uint2(in[src].w0, (left_dst << 2) | (in[src].w1 & 3u));
+    bool too_big = false;
+    auto leaf_desc = [&](uint32_t src) -> uint32_t {
+        const uint32_t cnt = in[src].w1 >> 2, off = in[src].w0;
+        if (cnt == 0) return (uint32_t)DESC_EXIT;
+        if (cnt == 1) {
+            if (leaf_idx[off] > DESC_MAX_PAYLOAD) too_big = true;
+            return DESC_SINGLE | (leaf_idx[off] & DESC_PAYLOAD);
         }
+        const size_t at = list.size();
+        if (at + cnt > DESC_MAX_PAYLOAD) {
+            too_big = true;
+            return (uint32_t)DESC_EXIT;
+        }
+        for (uint32_t k = 0; k < cnt; ++k) {
+            if (leaf_idx[off + k] > DESC_MAX_PAYLOAD) too_big = true;
+            list.push_back(leaf_idx[off + k] & DESC_PAYLOAD);
+        }
+        list.back() |= 0x80000000u;
+        return DESC_MULTI | (uint32_t)at;
     };
-    // breadth-first over whole levels while the level still fits the LDS cache
-    std::vector<std::pair<uint32_t, uint32_t>> level{{0u, 0u}}, next;  // (source index, destination index)
+    nodes.clear();
+    list.clear();
+    if (is_leaf(0)) {
+        root = (int32_t)leaf_desc(0);
+        return too_big ? "triangle index or leaf list beyond 2^30 - 3" : "";
+    }
+    uint32_t n_inner = 0;
+    for (uint32_t i = 0; i < n_nodes; ++i) n_inner += is_leaf(i) ? 0u : 1u;
+    nodes.assign(n_inner, make_uint4(0u, 0u, (uint32_t)DESC_EXIT, (uint32_t)DESC_EXIT));
+    root = 0;
     uint32_t used = 1;
-    top_count = 0;
-    std::vector<std::pair<uint32_t, uint32_t>> frontier;
-    for (;;) {
-        uint32_t children = 0;
-        for (auto& e : level)
-            if (!is_leaf(e.first)) children += 2;
-        const bool fits = used <= (uint32_t)LDS_TOP_NODES;  // this level is inside the cached prefix
-        if (fits) top_count = used;
-        if (!fits || children == 0 || used + children > (uint32_t)LDS_TOP_NODES) {
-            frontier = level;  // children of this level go depth-first
-            break;
-        }
-        next.clear();
-        for (auto& e : level) {
-            if (is_leaf(e.first)) {
-                emit(e.first, e.second, 0);
-            } else {
-                emit(e.first, e.second, used);
-                next.push_back({e.first + 1u, used});
-                next.push_back({in[e.first].w1 >> 2, used + 1u});
-                used += 2;
-            }
-        }
-        level.swap(next);
-    }
-    // depth-first below the frontier (explicit stack; siblings adjacent)
-    std::vector<std::pair<uint32_t, uint32_t>> stack(frontier.rbegin(), frontier.rend());
+    std::vector<std::pair<uint32_t, uint32_t>> stack{{0u, 0u}};  // (source index, destination index)
     while (!stack.empty()) {
-        auto e = stack.back();
+        const auto e = stack.back();
         stack.pop_back();
-        if (is_leaf(e.first)) {
-            emit(e.first, e.second, 0);
-        } else {
-            emit(e.first, e.second, used);
-            stack.push_back({in[e.first].w1 >> 2, used + 1u});
-            stack.push_back({e.first + 1u, used});
-            used += 2;
-        }
+        const uint32_t l = e.first + 1u, r = in[e.first].w1 >> 2;
+        const bool ll = is_leaf(l), rl = is_leaf(r);
+        const uint32_t dl = ll ? 0u : used++, dr = rl ? 0u : used++;  // inner siblings adjacent
+        const uint32_t desc_l = ll ? leaf_desc(l) : dl, desc_r = rl ? leaf_desc(r) : dr;
+        nodes[e.second] = make_uint4(in[e.first].w0, in[e.first].w1 & 3u, desc_l, desc_r);
+        if (!rl) stack.push_back({r, dr});
+        if (!ll) stack.push_back({l, dl});  // left subtree first: depth-first order
     }
+    return too_big ? "triangle index or leaf list beyond 2^30 - 3" : "";
 }
 
 template <bool ANY>
@@ -977,8 +943,8 @@ int launch_traverse(ptx_scene* sc, const ptx_ray* d_rays, const uint32_t* d_coun
     const bool count = (sc->flags & PTX_FLAG_COUNT_WORK) != 0 && work;
     TravArgs a{};
     a.nodes = sc->dev_nodes.p;
-    a.top_count = sc->top_count;
-    a.leaf_idx = sc->dev.leaf_idx;
+    a.leaf_list = sc->dev_leaf.p;
+    a.root = sc->root_desc;
     a.tris = sc->dev.tris;
     a.rays = d_rays;
     a.count_ptr = d_count;
@@ -1050,9 +1016,12 @@ int ptx_scene_create(const ptx_scene_desc* d, uint32_t flags, ptx_scene** out) {
     pack_triangles(d->triangles, d->n_triangles, recs);
     HIP_TRY(sc->nodes.upload(d->nodes, d->n_nodes));
     {
-        std::vector<uint2> dn;
-        relayout_nodes(d->nodes, d->n_nodes, d->leaf_indices, dn, sc->top_count);
+        std::vector<uint4> dn;
+        std::vector<uint32_t> dl;
+        const std::string big = build_device_tree(d->nodes, d->n_nodes, d->leaf_indices, dn, dl, sc->root_desc);
+        if (!big.empty()) return fail(PTX_E_LIMIT, "ptx_scene_create: " + big);
         HIP_TRY(sc->dev_nodes.upload(dn.data(), dn.size()));
+        HIP_TRY(sc->dev_leaf.upload(dl.data(), dl.size()));
     }
     HIP_TRY(sc->leaf_idx.upload(d->leaf_indices, d->n_leaf_indices));
     HIP_TRY(sc->tris.upload(recs.data(), recs.size()));

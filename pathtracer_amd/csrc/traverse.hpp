@@ -78,9 +78,10 @@ PTX_FN bool tri_test(const TriRec& r, float ox, float oy, float oz, float dx, fl
     const float p1 = axis == 2 ? hy : hz;
     const float b1x = r.f[3], b1y = r.f[4], b2x = r.f[5], b2y = r.f[6];
     const float sx = p0 - r.f[1], sy = p1 - r.f[2];
-    const float det = b1x * b2y - b2x * b1y;
-    if (det == 0.0f) return false;
-    const float inv = 1.0f / det;
+    // det = b1x*b2y - b2x*b1y and inv = 1/det depend on the triangle alone: pack_triangles() evaluates
+    // them once with the same IEEE operations and stores inv, or NaN for det == 0 (then u is NaN and the
+    // range test below rejects, as the reference's `det == 0` early return does).
+    const float inv = r.f[7];
     u = inv * (sx * b2y - b2x * sy);
     if (!(0.0f <= u && u <= 1.0f)) return false;
     v = inv * (b1x * sy - sx * b1y);
