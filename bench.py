@@ -137,7 +137,7 @@ def main():
             ext_ms, sh_ms = st["extend_ms"], st["shadow_ms"]
             out["extend_mrays_per_s"] = st["extend_rays"] / ext_ms / 1e3
             out["shadow_mrays_per_s"] = st["shadow_rays"] / sh_ms / 1e3 if sh_ms > 0 else None
-            out["kernel_ms"] = {"extend": ext_ms, "shadow": sh_ms, "shade": st["shade_ms"], "generate": st["generate_ms"]}
+            out["kernel_ms"] = {"extend": ext_ms, "shadow": sh_ms, "shade": st["shade_ms"], "generate": st["generate_ms"], "resolve_accumulate": st["other_ms"]}
             # algorithmic bytes per extend ray: 32 ray + 16 hit + 8 per inner node + 40 per triangle test,
             # node/triangle counts measured on this workload by a counting pass outside the timed region
             cdev = scene.upload(flags=pt.FLAG_COUNT_WORK)

@@ -122,6 +122,7 @@ typedef struct ptx_counters {
     uint64_t samples; /* pixel samples completed */
     uint64_t extend_launches, shadow_launches; /* kernel launches of each traversal class */
     double extend_ms, shadow_ms, shade_ms, generate_ms, total_ms; /* only with PTX_FLAG_TIME_KERNELS */
+    double other_ms; /* resolve + accumulate kernels */
 } ptx_counters;
 
 typedef struct ptx_scene ptx_scene; /* opaque: device-resident scene (one GPU) */

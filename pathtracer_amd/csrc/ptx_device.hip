@@ -341,6 +341,9 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                 if (COUNT) ++pf_end;
                 if (bi != PTX_MISS || t2 == t_end || sp == 0) {
                     if (ANY) {
+                        // (resolving here - radiance[path] += contribution for an unoccluded ray - was
+                        // measured slower than the separate streaming k_resolve: the scattered
+                        // read-modify-write stalls the whole wave)
                         a.occ[ridx] = bi != PTX_MISS ? 1 : 0;
                     } else {
                         const uint4 hv = bi != PTX_MISS ? make_uint4(bi, f2u(bt), f2u(bu), f2u(bv)) : make_uint4(PTX_MISS, 0u, 0u, 0u);
@@ -610,12 +613,15 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, ui
             pid_out[slot_n] = pid;
         }
         if (emit_shadow) {
-            st.sh_T[slot_s] = make_float4(T_old.x, T_old.y, T_old.z, u2f(pid));
+            // one light: the record is the product k_resolve would form (0 + c == c, so T * (0 + c) == T * c
+            // bit for bit) and no separate contribution array is written
+            if (NL == 1) st.sh_T[slot_s] = make_float4(T_old.x * sh_c[0].x, T_old.y * sh_c[0].y, T_old.z * sh_c[0].z, u2f(pid));
+            else st.sh_T[slot_s] = make_float4(T_old.x, T_old.y, T_old.z, u2f(pid));
             for (uint32_t l = 0; l < (NL ? (uint32_t)NL : n_lights); ++l) {
                 const size_t j = (size_t)slot_s * n_lights + l;
                 reinterpret_cast<float4*>(st.sh_rays)[2 * j] = make_float4(point_above.x, point_above.y, point_above.z, 0.0f);
                 reinterpret_cast<float4*>(st.sh_rays)[2 * j + 1] = make_float4(sh_dir[l].x, sh_dir[l].y, sh_dir[l].z, 1.0f);
-                st.sh_contrib[j] = make_float4(sh_c[l].x, sh_c[l].y, sh_c[l].z, 0.0f);
+                if (NL != 1) st.sh_contrib[j] = make_float4(sh_c[l].x, sh_c[l].y, sh_c[l].z, 0.0f);
             }
         }
     }
@@ -629,6 +635,16 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(RenderState st, uint32_t boun
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
         const float4 T = st.sh_T[i];
         const uint32_t pid = f2u(T.w);
+        if (n_lights == 1u) {  // k_shade<1> stored transport * contribution
+            if (!st.sh_occ[i]) {
+                float4 R = st.radiance[pid];
+                R.x = R.x + T.x;
+                R.y = R.y + T.y;
+                R.z = R.z + T.z;
+                st.radiance[pid] = R;
+            }
+            continue;
+        }
         V3 incoming = v3(0.0f, 0.0f, 0.0f);
         for (uint32_t l = 0; l < n_lights; ++l) {
             const size_t j = (size_t)i * n_lights + l;
@@ -1223,11 +1239,14 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
                 else k_shade<0><<<grid, BLOCK, 0, stream>>>(sc->dev, st, b);
             }
             if (L > 0) {
-                Timed tm(sc, stream, KC_SHADOW);
-                ++sc->shadow_launches;
-                rc = launch_traverse<true>(sc, st.sh_rays, st.sh_counts + (b - 1), L, 0, nullptr, st.sh_occ,
-                                           st.cursors + 2 * (b - 1) + 1, p.spill.p, sc->totals.p + 4, stream);
-                if (rc) return rc;
+                {
+                    Timed tm(sc, stream, KC_SHADOW);
+                    ++sc->shadow_launches;
+                    rc = launch_traverse<true>(sc, st.sh_rays, st.sh_counts + (b - 1), L, 0, nullptr, st.sh_occ,
+                                               st.cursors + 2 * (b - 1) + 1, p.spill.p, sc->totals.p + 4, stream);
+                    if (rc) return rc;
+                }
+                Timed tm(sc, stream, KC_OTHER);
                 k_resolve<<<grid, BLOCK, 0, stream>>>(st, b, L);
             }
         }
@@ -1316,6 +1335,7 @@ int ptx_stats(ptx_scene* sc, ptx_counters* out) {
     out->extend_launches = sc->extend_launches;
     out->shadow_launches = sc->shadow_launches;
     out->generate_ms = sc->class_ms[KC_GENERATE];
+    out->other_ms = sc->class_ms[KC_OTHER];
     out->extend_ms = sc->class_ms[KC_EXTEND];
     out->shade_ms = sc->class_ms[KC_SHADE];
     out->shadow_ms = sc->class_ms[KC_SHADOW];
