@@ -215,6 +215,10 @@ int ptx_render_device(ptx_scene* scene, const ptx_pinhole* camera, uint64_t seed
                       uint32_t sample_count, float* d_accum, void* stream);
 /* Samples kept in flight per launch batch (default chosen from the image size). */
 int ptx_set_batch_samples(ptx_scene* scene, uint32_t samples_per_batch);
+/* Sample batches rendered concurrently, each on a HIP stream of its own (1..8, default 2 or the
+ * PTX_PIPES environment variable).  With 1 every kernel has the GPU to itself, which is what a
+ * per-kernel measurement wants; results do not depend on it.  No counterpart in the reference. */
+int ptx_set_pipelines(ptx_scene* scene, uint32_t pipelines);
 
 /* Queue lengths of the most recent render batch: extend_counts[b] / shadow_counts[b] = rays of bounce b+1
  * (shadow counts are paths; multiply by the number of lights).  n = capacity of each array. */

@@ -326,6 +326,9 @@ class DeviceScene:
     def set_batch_samples(self, n):
         _check(lib().ptx_set_batch_samples(self._h, n))
 
+    def set_pipelines(self, n):
+        _check(lib().ptx_set_pipelines(self._h, n))
+
     def render(self, pinhole, sample_count, seed=0, first_sample=0, accum=None, progress=None):
         """Adds samples [first_sample, first_sample+sample_count) into accum (H x W x 3 float32)."""
         if accum is None:

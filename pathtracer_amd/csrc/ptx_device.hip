@@ -861,7 +861,9 @@ int ensure_render_state(ptx_scene* sc, size_t paths) {
         return PTX_OK;
     HIP_TRY(hipDeviceSynchronize());
     if (!sc->ev_fork) HIP_TRY(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
+    if (paths < sc->cap_paths) paths = sc->cap_paths;  // every pipeline, old or new, holds the high-water mark
     sc->pipes.resize(sc->n_pipes);
+    sc->last_pipe = 0;
     for (auto& up : sc->pipes) {
         if (!up) {
             up = std::make_unique<ptx_scene::Pipe>();
@@ -1148,6 +1150,15 @@ int ptx_intersect_batch(ptx_scene* sc, const ptx_ray* rays, size_t n, ptx_hit* h
 int ptx_set_batch_samples(ptx_scene* sc, uint32_t samples_per_batch) {
     if (!sc) return fail(PTX_E_ARG, "ptx_set_batch_samples: null scene");
     sc->batch_samples = samples_per_batch;
+    return PTX_OK;
+}
+
+int ptx_set_pipelines(ptx_scene* sc, uint32_t n) {
+    int rc = check_scene(sc, "ptx_set_pipelines");
+    if (rc) return rc;
+    if (n < 1 || n > 8) return fail(PTX_E_ARG, "ptx_set_pipelines: 1..8 pipelines");
+    HIP_TRY(hipDeviceSynchronize());
+    sc->n_pipes = n;  // the pipelines are (re)built by the next render call
     return PTX_OK;
 }
 
