@@ -155,16 +155,19 @@ def main():
             b_ray = 48.0 + 8.0 * nodes_per_ray + 40.0 * tris_per_ray
             launches = st["extend_launches"]
             achieved = st["extend_rays"] * b_ray / (ext_ms * 1e-3) / 1e9
-            # the same kernel with the GPU to itself: with two sample batches in flight (the default) launches of
-            # different batches share the CUs, so the per-launch durations above are ~2x the kernel's own time
-            dev.set_pipelines(1)
-            dev.set_batch_samples(min(spp, 64))
-            dev.stats_reset()
-            tmp.zero_()
-            dev.render_device(pinhole, min(spp, 64), tmp.data_ptr(), seed=0, first_sample=base_sample, stream=stream)
-            torch.cuda.synchronize()
-            ex = dev.stats()
-            ex_achieved = ex["extend_rays"] * b_ray / (ex["extend_ms"] * 1e-3) / 1e9
+            # with several sample batches in flight (ptx_set_pipelines > 1; the default is 1) launches of different
+            # batches share the CUs and the per-launch durations above are inflated: repeat on one batch alone
+            pipelines = int(os.environ.get("PTX_PIPES", "1"))
+            ex = None
+            if pipelines > 1:
+                dev.set_pipelines(1)
+                dev.set_batch_samples(min(spp, 64))
+                dev.stats_reset()
+                tmp.zero_()
+                dev.render_device(pinhole, min(spp, 64), tmp.data_ptr(), seed=0, first_sample=base_sample, stream=stream)
+                torch.cuda.synchronize()
+                ex = dev.stats()
+                ex_achieved = ex["extend_rays"] * b_ray / (ex["extend_ms"] * 1e-3) / 1e9
             hbm_per_ray = MEASURED_EXTEND_HBM_BYTES_PER_RAY.get(args.scene) if (W, H) == (1080, 1080) else None
             out["roofline"] = {
                 "kernel": "k_traverse<nearest> (extend)",
@@ -181,13 +184,14 @@ def main():
                 "launches": launches,
                 "avg_launch_ms": ext_ms / max(launches, 1),
                 "compulsory_hbm_frac": st["extend_rays"] * 48.0 / (ext_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "concurrent_batches": int(os.environ.get("PTX_PIPES", "2")),
-                "exclusive": {"achieved": ex_achieved, "frac": ex_achieved / HBM_PEAK_GBS,
-                              "extend_mrays_per_s": ex["extend_rays"] / ex["extend_ms"] / 1e3,
-                              "shadow_mrays_per_s": ex["shadow_rays"] / ex["shadow_ms"] / 1e3 if ex["shadow_ms"] > 0 else None,
-                              "avg_launch_ms": ex["extend_ms"] / max(ex["extend_launches"], 1),
-                              "sample": "one batch of %d spp alone on the GPU (ptx_set_pipelines(1)), outside the timed region" % min(spp, 64)},
+                "concurrent_batches": pipelines,
             }
+            if ex is not None:
+                out["roofline"]["exclusive"] = {
+                    "achieved": ex_achieved, "frac": ex_achieved / HBM_PEAK_GBS,
+                    "extend_mrays_per_s": ex["extend_rays"] / ex["extend_ms"] / 1e3,
+                    "avg_launch_ms": ex["extend_ms"] / max(ex["extend_launches"], 1),
+                    "sample": "one batch of %d spp alone on the GPU (ptx_set_pipelines(1)), outside the timed region" % min(spp, 64)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(obj, W, H, args.max_bounces)
         if args.save:

@@ -184,6 +184,9 @@ __device__ inline void wave_add(unsigned long long* dst, uint32_t v) {
 #ifndef PTX_LDS_DEPTH
 #define PTX_LDS_DEPTH 8
 #endif
+#ifndef PTX_TOP_NODES
+#define PTX_TOP_NODES 255
+#endif
 #ifndef PTX_REFILL_IDLE
 #define PTX_REFILL_IDLE 16
 #endif
@@ -198,6 +201,7 @@ __device__ inline void wave_add(unsigned long long* dst, uint32_t v) {
 #endif
 constexpr int TBLOCK = PTX_TBLOCK;        // threads per traversal workgroup
 constexpr int LDS_DEPTH = PTX_LDS_DEPTH;  // stack levels kept in LDS
+constexpr int TOP_NODES = PTX_TOP_NODES;  // inner nodes [0, TOP_NODES) = the top of the tree, served from LDS
 constexpr uint32_t REFILL_IDLE = PTX_REFILL_IDLE;
 constexpr uint32_t TRI_BATCH_NEAREST = PTX_TRI_BATCH;  // lanes that must wait in a leaf before the triangle step runs
 constexpr uint32_t TRI_BATCH_ANYHIT = PTX_TRI_BATCH_ANY;
@@ -206,8 +210,11 @@ constexpr int32_t DESC_EXIT = -1, DESC_IDLE = -2;
 constexpr uint32_t DESC_MULTI = 0x80000000u, DESC_SINGLE = 0xC0000000u, DESC_PAYLOAD = 0x3FFFFFFFu;
 constexpr uint32_t DESC_MAX_PAYLOAD = 0x3FFFFFFDu;  // keeps DESC_SINGLE | idx clear of the two specials
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 struct TravArgs {
     const uint4* nodes;        // inner nodes, device layout
+    uint32_t top_n;            // nodes [0, top_n) are copied into LDS by every workgroup (<= TOP_NODES)
     const uint32_t* leaf_list; // triangle indices of the multi-triangle leaves, last one flagged
     const TriRec* tris;
     const ptx_ray* rays;
@@ -225,11 +232,23 @@ struct TravArgs {
 
 template <bool ANY, bool COUNT>
 __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
-    __shared__ uint2 s_stack[LDS_DEPTH][TBLOCK];
+    // Level 0 of a lane's stack column is a sentinel {-, t_end}: the entry "below" the first real entry, so a
+    // pop needs no special case for the segment end of an emptied stack.  Stack positions are kept as LDS
+    // byte offsets (one add per push/pop, no address arithmetic).
+    __shared__ uint2 s_stack[LDS_DEPTH + 1][TBLOCK];
+    __shared__ uint4 s_top[TOP_NODES > 0 ? TOP_NODES : 1];
+    char* const s_base = reinterpret_cast<char*>(&s_stack[0][0]);
+    constexpr uint32_t LVL = TBLOCK * 8u;  // bytes per stack level
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t gtid = blockIdx.x * TBLOCK + tid;
+    const uint32_t so0 = tid * 8u;                    // this lane's sentinel
+    const uint32_t so_last = so0 + LVL * LDS_DEPTH;   // its last LDS level; deeper levels live in a.spill
     const uint32_t count = a.count_ptr ? *a.count_ptr * a.count_scale : a.fixed_count;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int32_t top_n = (int32_t)a.top_n;
+    const uint32_t top_base = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint4*)s_top);
+    for (uint32_t i = tid; i < a.top_n; i += TBLOCK) s_top[i] = a.nodes[i];
+    __syncthreads();
     // window size: ~4 windows per wave over the launch, 64..512 rays, multiple of 64
     uint32_t chunk = count / (gridDim.x * (TBLOCK / 64) * 4u);
     chunk = chunk < 64u ? 64u : (chunk > 512u ? 512u : (chunk & ~63u));
@@ -238,11 +257,13 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
     int32_t cur = DESC_IDLE;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, t_end = 0, t1 = 0, t2 = 0;
     uint32_t ridx = 0;
-    int sp = 0;
+    uint32_t so = so0 + LVL;  // offset of the next free stack slot; so0 + LVL == empty
     uint32_t bi = PTX_MISS;
-    float bt = 0.0f, bu = 0.0f, bv = 0.0f;
+    float bt = 0.0f, bu = 0.0f, bv = 0.0f;  // stay 0 while bi == PTX_MISS
     uint32_t n_inner = 0, n_tris = 0;
     uint32_t pf_iter = 0, pf_walk = 0, pf_tri_iter = 0, pf_tri = 0, pf_end_iter = 0, pf_end = 0, pf_refill = 0, pf_live = 0;
+#define PTX_SLOT(off) (*reinterpret_cast<uint2*>(s_base + (off)))
+#define PTX_SPILL(off) a.spill[(size_t)(((off) - so_last) / LVL - 1u) * a.spill_stride + gtid]
 
     for (;;) {
         if (COUNT) pf_refill += lane == 0 ? 1u : 0u;
@@ -272,8 +293,10 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                 ox = ra.x, oy = ra.y, oz = ra.z, t1 = ra.w;
                 dx = rb.x, dy = rb.y, dz = rb.z, t2 = t_end = rb.w;
                 cur = a.root;
-                sp = 0;
+                so = so0 + LVL;
+                PTX_SLOT(so0) = make_uint2(0u, f2u(t_end));
                 bi = PTX_MISS;
+                bt = bu = bv = 0.0f;
             }
             lo += n_idle < avail ? n_idle : avail;
         }
@@ -283,7 +306,16 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
         for (;;) {
             if (COUNT) pf_iter += lane == 0 ? 1u : 0u, pf_walk += cur >= 0 ? 1u : 0u, pf_live += cur != DESC_IDLE ? 1u : 0u;
             if (cur >= 0) {  // node visit, kdtree/src/lib.rs:105-129
-                const uint4 nd = a.nodes[cur];
+                uint4 nd;  // the top of the tree comes from LDS: no L1 tag lookup, a fifth of the latency
+                if (cur < top_n) {
+                    // written as an instruction: as C++ the two loads are merged into one flat_load of a
+                    // selected pointer, which goes through the vector memory path for LDS addresses too
+                    u32x4 v;
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(top_base + ((uint32_t)cur << 4)) : "memory");
+                    nd = make_uint4(v.x, v.y, v.z, v.w);
+                } else {
+                    nd = a.nodes[cur];
+                }
                 if (COUNT) ++n_inner;
                 const uint32_t axis = nd.y;
                 const float dist = u2f(nd.x);
@@ -300,9 +332,9 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                 next = parallel ? (oa <= dist ? nd.z : nd.w) : next;
                 if (push) {
                     const uint2 e = make_uint2(far_d, f2u(t));
-                    if (sp < LDS_DEPTH) s_stack[sp][tid] = e;
-                    else a.spill[(size_t)(sp - LDS_DEPTH) * a.spill_stride + gtid] = e;
-                    ++sp;
+                    if (so <= so_last) PTX_SLOT(so) = e;
+                    else PTX_SPILL(so) = e;
+                    so += LVL;
                     t2 = t;
                 }
                 cur = (int32_t)next;
@@ -339,37 +371,39 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
             if (COUNT && __any(cur == DESC_EXIT)) pf_end_iter += lane == 0 ? 1u : 0u;
             if (cur == DESC_EXIT) {  // leaving a leaf: kdtree/src/lib.rs:95-103
                 if (COUNT) ++pf_end;
-                if (bi != PTX_MISS || t2 == t_end || sp == 0) {
+                // The pop is read unconditionally (LDS offsets clamped into the column; for an empty stack
+                // the "top" is the sentinel and the values go unused) and selected afterwards.
+                const uint32_t st = so - LVL;  // top entry, or the sentinel when the stack is empty
+                const uint32_t sb = st - LVL;  // the entry below it (wraps when st is the sentinel: clamped)
+                uint2 top = PTX_SLOT(st < so_last ? st : so_last);
+                uint32_t tb = PTX_SLOT(sb < so_last ? sb : so_last).y;
+                if (st > so_last) {  // rare: the top (and maybe the entry below) lives in the spill area
+                    top = PTX_SPILL(st);
+                    if (sb > so_last) tb = PTX_SPILL(sb).y;
+                }
+                const bool done = bi != PTX_MISS || t2 == t_end || st == so0;
+                if (done) {
                     if (ANY) {
                         // (resolving here - radiance[path] += contribution for an unoccluded ray - was
                         // measured slower than the separate streaming k_resolve: the scattered
                         // read-modify-write stalls the whole wave)
                         a.occ[ridx] = bi != PTX_MISS ? 1 : 0;
                     } else {
-                        const uint4 hv = bi != PTX_MISS ? make_uint4(bi, f2u(bt), f2u(bu), f2u(bv)) : make_uint4(PTX_MISS, 0u, 0u, 0u);
-                        reinterpret_cast<uint4*>(a.hits)[ridx] = hv;
+                        reinterpret_cast<uint4*>(a.hits)[ridx] = make_uint4(bi, f2u(bt), f2u(bu), f2u(bv));
                     }
-                    cur = DESC_IDLE;
-                } else {
-                    --sp;
-                    // the LDS reads are unconditional (clamped level), the spill reads a rare branch on top
-                    const int below = sp > 0 ? sp - 1 : 0;
-                    uint2 e = s_stack[sp < LDS_DEPTH ? sp : LDS_DEPTH - 1][tid];
-                    uint32_t tb = s_stack[below < LDS_DEPTH ? below : LDS_DEPTH - 1][tid].y;
-                    if (sp >= LDS_DEPTH) {
-                        e = a.spill[(size_t)(sp - LDS_DEPTH) * a.spill_stride + gtid];
-                        if (below >= LDS_DEPTH) tb = a.spill[(size_t)(below - LDS_DEPTH) * a.spill_stride + gtid].y;
-                    }
-                    cur = (int32_t)e.x;
-                    t1 = u2f(e.y);
-                    t2 = sp > 0 ? u2f(tb) : t_end;
                 }
+                cur = done ? DESC_IDLE : (int32_t)top.x;
+                t1 = done ? t1 : u2f(top.y);
+                t2 = done ? t2 : u2f(tb);
+                so = done ? so : st;
             }
             const uint32_t live = (uint32_t)__popcll(__ballot(cur != DESC_IDLE));
             if (live == 0) break;
             if (!(drained && lo >= hi) && live <= 64u - REFILL_IDLE) break;
         }
     }
+#undef PTX_SLOT
+#undef PTX_SPILL
     if (COUNT) {
         wave_add(&a.work[0], n_inner);
         wave_add(&a.work[1], n_tris);
@@ -739,6 +773,7 @@ struct ptx_scene {
     DevBuf<uint4> dev_nodes;     // traversal layout (see k_traverse)
     DevBuf<uint32_t> dev_leaf;  // triangle lists of the multi-triangle leaves, last entry flagged
     int32_t root_desc = DESC_EXIT;
+    uint32_t top_n = 0;  // inner nodes served from LDS
     int tgrid = 1024;  // traversal workgroups (TBLOCK threads each)
     DevBuf<uint32_t> leaf_idx;
     DevBuf<TriRec> tris;
@@ -774,7 +809,7 @@ struct ptx_scene {
         }
     };
     std::vector<std::unique_ptr<Pipe>> pipes;
-    uint32_t n_pipes = 2;
+    uint32_t n_pipes = 1;
     int last_pipe = 0;
     hipEvent_t ev_fork = nullptr;
     DevBuf<uint2> spill;  // of the *_batch entry points
@@ -906,7 +941,8 @@ int check_scene(ptx_scene* sc, const char* who) {
 // Re-index the ABI's preorder tree into the device layout described above k_traverse.  Returns an empty
 // string, or why the tree does not fit the descriptor fields.
 std::string build_device_tree(const ptx_kdnode* in, uint32_t n_nodes, const uint32_t* leaf_idx, std::vector<uint4>& nodes,
-                              std::vector<uint32_t>& list, int32_t& root) {
+                              std::vector<uint32_t>& list, int32_t& root, uint32_t& top_n) {
+    top_n = 0;
     auto is_leaf = [&](uint32_t i) { return (in[i].w1 & 3u) == 3u; };
     bool too_big = false;
     auto leaf_desc = [&](uint32_t src) -> uint32_t {
@@ -939,17 +975,37 @@ std::string build_device_tree(const ptx_kdnode* in, uint32_t n_nodes, const uint
     nodes.assign(n_inner, make_uint4(0u, 0u, (uint32_t)DESC_EXIT, (uint32_t)DESC_EXIT));
     root = 0;
     uint32_t used = 1;
-    std::vector<std::pair<uint32_t, uint32_t>> stack{{0u, 0u}};  // (source index, destination index)
-    while (!stack.empty()) {
-        const auto e = stack.back();
-        stack.pop_back();
-        const uint32_t l = e.first + 1u, r = in[e.first].w1 >> 2;
+    auto emit = [&](uint32_t src, uint32_t dst, std::vector<std::pair<uint32_t, uint32_t>>& out, bool left_last) {
+        const uint32_t l = src + 1u, r = in[src].w1 >> 2;
         const bool ll = is_leaf(l), rl = is_leaf(r);
         const uint32_t dl = ll ? 0u : used++, dr = rl ? 0u : used++;  // inner siblings adjacent
         const uint32_t desc_l = ll ? leaf_desc(l) : dl, desc_r = rl ? leaf_desc(r) : dr;
-        nodes[e.second] = make_uint4(in[e.first].w0, in[e.first].w1 & 3u, desc_l, desc_r);
-        if (!rl) stack.push_back({r, dr});
-        if (!ll) stack.push_back({l, dl});  // left subtree first: depth-first order
+        nodes[dst] = make_uint4(in[src].w0, in[src].w1 & 3u, desc_l, desc_r);
+        if (left_last) {  // for a LIFO: right pushed first so that the left subtree is numbered first
+            if (!rl) out.push_back({r, dr});
+            if (!ll) out.push_back({l, dl});
+        } else {
+            if (!ll) out.push_back({l, dl});
+            if (!rl) out.push_back({r, dr});
+        }
+    };
+    // breadth-first while the node being emitted is inside the LDS prefix ...
+    std::vector<std::pair<uint32_t, uint32_t>> queue{{0u, 0u}};
+    size_t head = 0;
+    while (head < queue.size() && queue[head].second < (uint32_t)TOP_NODES) {
+        const auto e = queue[head++];
+        emit(e.first, e.second, queue, false);
+    }
+    top_n = used < (uint32_t)TOP_NODES ? used : (uint32_t)TOP_NODES;
+    if (top_n > n_inner) top_n = n_inner;
+    // ... depth-first below it (every pending node roots a contiguous subtree)
+    for (; head < queue.size(); ++head) {
+        std::vector<std::pair<uint32_t, uint32_t>> stack{queue[head]};
+        while (!stack.empty()) {
+            const auto e = stack.back();
+            stack.pop_back();
+            emit(e.first, e.second, stack, true);
+        }
     }
     return too_big ? "triangle index or leaf list beyond 2^30 - 3" : "";
 }
@@ -962,6 +1018,7 @@ int launch_traverse(ptx_scene* sc, const ptx_ray* d_rays, const uint32_t* d_coun
     TravArgs a{};
     a.nodes = sc->dev_nodes.p;
     a.leaf_list = sc->dev_leaf.p;
+    a.top_n = sc->top_n;
     a.root = sc->root_desc;
     a.tris = sc->dev.tris;
     a.rays = d_rays;
@@ -1036,7 +1093,7 @@ int ptx_scene_create(const ptx_scene_desc* d, uint32_t flags, ptx_scene** out) {
     {
         std::vector<uint4> dn;
         std::vector<uint32_t> dl;
-        const std::string big = build_device_tree(d->nodes, d->n_nodes, d->leaf_indices, dn, dl, sc->root_desc);
+        const std::string big = build_device_tree(d->nodes, d->n_nodes, d->leaf_indices, dn, dl, sc->root_desc, sc->top_n);
         if (!big.empty()) return fail(PTX_E_LIMIT, "ptx_scene_create: " + big);
         HIP_TRY(sc->dev_nodes.upload(dn.data(), dn.size()));
         HIP_TRY(sc->dev_leaf.upload(dl.data(), dl.size()));
@@ -1172,14 +1229,14 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
     if (n_pixels64 > (1ull << 27)) return fail(PTX_E_LIMIT, "ptx_render: image larger than 2^27 pixels");
     if ((uint64_t)first_sample + sample_count > 0xFFFFFFFFull) return fail(PTX_E_LIMIT, "ptx_render: sample index overflow");
     const uint32_t n_pixels = (uint32_t)n_pixels64;
-    // Batch size: large batches amortise the long-ray tail of every launch (measured at 1080^2: 5 -> 64
-    // samples per batch raises the traversal kernels from 2.5 to ~7 Grays/s), and the batches of one call
-    // are spread evenly over the pipelines so that all of them run concurrently.  ~230 B of queue state
-    // per path: the default budget of 160 Mi paths in flight is ~37 GB of the 288 GB of HBM.
+    // Batch size: large batches amortise the long-ray tail of every launch (measured at 1080^2: 5 -> 64 ->
+    // 128 -> 192 samples per batch raises the traversal kernels from 2.5 to ~7 / 11.2 / 11.6 Grays/s).  ~230 B
+    // of queue state per path: the default budget of 240 Mi paths in flight is ~58 GB of the 288 GB of HBM.
+    // With more than one pipeline (ptx_set_pipelines) the batches of a call are spread evenly over them.
     const uint32_t n_pipes = sc->n_pipes;
     uint32_t S = sc->batch_samples;
     if (S == 0) {
-        const uint64_t budget = (160ull << 20) / ((uint64_t)n_pipes * n_pixels);
+        const uint64_t budget = (240ull << 20) / ((uint64_t)n_pipes * n_pixels);
         S = (uint32_t)(budget < 1 ? 1 : (budget > 256 ? 256 : budget));
         const uint32_t per_pipe = (sample_count + n_pipes - 1) / n_pipes;
         if (per_pipe > 0 && per_pipe < S) S = per_pipe;

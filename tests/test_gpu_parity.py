@@ -131,6 +131,14 @@ def test_render_bit_exact_vs_oracle_counter_mode(name, w, h, spp, bounces):
     dev.set_batch_samples(1)
     again = dev.render(scene.pinhole(w, h), spp, seed=77, first_sample=5)
     assert again.tobytes() == got.tobytes()
+    # nor must the number of batches in flight: two pipelines (streams) add the samples in the same order
+    dev.set_pipelines(2)
+    again = dev.render(scene.pinhole(w, h), spp, seed=77, first_sample=5)
+    assert again.tobytes() == got.tobytes()
+    dev.set_pipelines(1)
+    dev.set_batch_samples(0)
+    again = dev.render(scene.pinhole(w, h), spp, seed=77, first_sample=5)
+    assert again.tobytes() == got.tobytes()
     dev.close()
 
 
