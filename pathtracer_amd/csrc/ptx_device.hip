@@ -30,7 +30,13 @@ using namespace ptx;
 
 namespace {
 
-constexpr int BLOCK = 256;
+#ifndef PTX_WAVE_SLOTS
+#define PTX_WAVE_SLOTS 0
+#endif
+#ifndef PTX_BLOCK
+#define PTX_BLOCK 256
+#endif
+constexpr int BLOCK = PTX_BLOCK;
 constexpr int WAVES = BLOCK / 64;
 
 struct DevMaterial {
@@ -65,8 +71,10 @@ struct RenderState {
     float4* sh_T;        // [i] {transport before this bounce's update, bits(pid)}
     float4* sh_contrib;  // [i * n_lights + l] {bsdf * emitted * |cos|, 0}
     uint8_t* sh_occ;     // [i * n_lights + l] 1 = occluded
-    uint32_t* ext_counts;  // [max_bounces + 1] extend queue lengths
-    uint32_t* sh_counts;   // [max_bounces]     shadow queue lengths (paths; x n_lights rays)
+    // Queue lengths as pairs, so that k_shade bumps both of its output queues with ONE 64-bit atomic:
+    // qcounts[2k] = extend queue of bounce k+1 (k = 0..max_bounces), qcounts[2b+1] = shadow queue of bounce b
+    // (paths; x n_lights rays).
+    uint32_t* qcounts;
     uint32_t* cursors;     // [2 * max_bounces] work cursors of the persistent traversal launches
     unsigned long long* totals;  // extend rays, shadow rays, ext inner, ext tris, sh inner, sh tris
     ptx_pinhole cam;
@@ -117,9 +125,11 @@ __device__ inline uint32_t block_slot(bool flag, uint32_t* counter, uint32_t* ld
     return slot;
 }
 
-// The same for two queues at once (one barrier sequence instead of two).
-__device__ inline void block_slot2(bool f0, bool f1, uint32_t* counter0, uint32_t* counter1,
-                                   uint32_t* lds /* 2 * WAVES + 2 */, uint32_t& slot0, uint32_t& slot1) {
+// The same for two queues at once: one barrier sequence, and ONE 64-bit atomic on the pair of queue
+// counters {low word: queue 0, high word: queue 1}.  The atomic on the (hot, shared by every workgroup)
+// counter address is what bounds k_shade: halving their number took 25 % off the kernel.
+__device__ inline void block_slot2(bool f0, bool f1, unsigned long long* counter_pair, uint32_t* lds /* 2 * WAVES + 2 */,
+                                   uint32_t& slot0, uint32_t& slot1) {
     const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -129,20 +139,39 @@ __device__ inline void block_slot2(bool f0, bool f1, uint32_t* counter0, uint32_
         lds[WAVES + 1 + wave] = (uint32_t)__popcll(b1);
     }
     __syncthreads();
-    if (threadIdx.x < 2) {
-        uint32_t* l = lds + threadIdx.x * (WAVES + 1);
-        uint32_t total = 0;
+    if (threadIdx.x == 0) {
+        uint32_t t0 = 0, t1 = 0;
         for (int w = 0; w < WAVES; ++w) {
-            uint32_t c = l[w];
-            l[w] = total;
-            total += c;
+            const uint32_t c0 = lds[w], c1 = lds[WAVES + 1 + w];
+            lds[w] = t0;
+            lds[WAVES + 1 + w] = t1;
+            t0 += c0;
+            t1 += c1;
         }
-        l[WAVES] = total ? atomicAdd(threadIdx.x == 0 ? counter0 : counter1, total) : 0u;
+        unsigned long long base = 0ull;
+        if (t0 | t1) base = atomicAdd(counter_pair, (unsigned long long)t0 | ((unsigned long long)t1 << 32));
+        lds[WAVES] = (uint32_t)base;
+        lds[2 * WAVES + 1] = (uint32_t)(base >> 32);
     }
     __syncthreads();
     slot0 = lds[WAVES] + lds[wave] + before0;
     slot1 = lds[2 * WAVES + 1] + lds[WAVES + 1 + wave] + before1;
     __syncthreads();  // lds is reused by the next iteration
+}
+
+// Wave-level variant: no barrier, no LDS; one 64-bit atomic per wave.  Queue order then follows the order
+// in which waves arrive (results do not depend on it: every path owns its state slot).
+__device__ inline void wave_slot2(bool f0, bool f1, unsigned long long* counter_pair, uint32_t& slot0, uint32_t& slot1) {
+    const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned long long base = 0ull;
+    if (lane == 0 && (b0 | b1))
+        base = atomicAdd(counter_pair, (unsigned long long)__popcll(b0) | ((unsigned long long)__popcll(b1) << 32));
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+    slot0 = lo + (uint32_t)__popcll(b0 & lt);
+    slot1 = hi + (uint32_t)__popcll(b1 & lt);
 }
 
 __device__ inline void wave_add(unsigned long long* dst, uint32_t v) {
@@ -442,7 +471,7 @@ __global__ __launch_bounds__(BLOCK) void k_generate(RenderState st) {
         st.transport[pid] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
         st.radiance[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) st.ext_counts[0] = total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st.qcounts[0] = total;
 }
 
 struct Bsdf {
@@ -553,7 +582,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, ui
     const uint32_t* __restrict__ pid_in = st.pids[q];
     ptx_ray* __restrict__ rays_out = st.rays[q ^ 1u];
     uint32_t* __restrict__ pid_out = st.pids[q ^ 1u];
-    const uint32_t count = st.ext_counts[bounce - 1u];
+    const uint32_t count = st.qcounts[2u * (bounce - 1u)];
     const uint32_t n_lights = NL ? (uint32_t)NL : sc.n_lights;
     const uint32_t base = ptx_dim_base(bounce, n_lights);
     constexpr int MAXL = NL ? NL : PTX_MAX_LIGHTS;
@@ -639,7 +668,11 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, ui
         // one compaction pass for both queues: wave ballots, LDS prefix over the waves, ONE atomic per
         // workgroup and queue
         uint32_t slot_n, slot_s;
-        block_slot2(emit_next, emit_shadow, &st.ext_counts[bounce], &st.sh_counts[bounce - 1u], lds, slot_n, slot_s);
+#if PTX_WAVE_SLOTS
+        wave_slot2(emit_next, emit_shadow, reinterpret_cast<unsigned long long*>(st.qcounts + 2u * bounce), slot_n, slot_s);
+#else
+        block_slot2(emit_next, emit_shadow, reinterpret_cast<unsigned long long*>(st.qcounts + 2u * bounce), lds, slot_n, slot_s);
+#endif
         if (emit_next) {
             reinterpret_cast<float4*>(rays_out)[2 * (size_t)slot_n] = make_float4(next_o.x, next_o.y, next_o.z, 0.0f);
             reinterpret_cast<float4*>(rays_out)[2 * (size_t)slot_n + 1] =
@@ -665,7 +698,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, ui
 // unoccluded contributions, in MTL light order (pathtracer.rs:68-86).  One path per lane; the occlusion
 // flags come from the any-hit traversal launch over the shadow-ray queue.
 __global__ __launch_bounds__(BLOCK) void k_resolve(RenderState st, uint32_t bounce, uint32_t n_lights) {
-    const uint32_t count = st.sh_counts[bounce - 1u];
+    const uint32_t count = st.qcounts[2u * bounce + 1u];
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
         const float4 T = st.sh_T[i];
         const uint32_t pid = f2u(T.w);
@@ -717,8 +750,8 @@ __global__ void k_tally(RenderState st, uint32_t max_bounces, uint32_t n_lights)
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         unsigned long long e = 0, s = 0;
         for (uint32_t b = 0; b < max_bounces; ++b) {
-            e += st.ext_counts[b];
-            s += (unsigned long long)st.sh_counts[b] * n_lights;
+            e += st.qcounts[2u * b];
+            s += (unsigned long long)st.qcounts[2u * b + 3u] * n_lights;
         }
         st.totals[0] += e;
         st.totals[1] += s;
@@ -782,6 +815,7 @@ struct ptx_scene {
     std::vector<std::unique_ptr<DevBuf<float>>> textures;
     DevScene dev{};
     int grid = 2048;
+    int shade_grid = 2048;  // k_shade needs more registers: its grid is sized by the occupancy it really gets
 
     // render state (allocated on first render, grown on demand)
     uint32_t batch_samples = 0;  // 0 = choose from the image size
@@ -1077,6 +1111,21 @@ int ptx_scene_create(const ptx_scene_desc* d, uint32_t flags, ptx_scene** out) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, sc->device));
     sc->grid = prop.multiProcessorCount * 8;
+    {
+        // grid-stride kernels want exactly one resident round of workgroups: a ninth block per CU that only
+        // starts when another has finished doubles the kernel's time
+        int per_cu = 0;
+        const uint32_t L = d->n_lights;
+        hipError_t oe = L == 1   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shade<1>, BLOCK, 0)
+                        : L == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shade<2>, BLOCK, 0)
+                        : L == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shade<4>, BLOCK, 0)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shade<0>, BLOCK, 0);
+        if (oe != hipSuccess || per_cu < 1) per_cu = 4;
+        if (per_cu > 8) per_cu = 8;
+        if (const char* ev = getenv("PTX_SHADE_PER_CU")) per_cu = atoi(ev) > 0 ? atoi(ev) : per_cu;
+        if (getenv("PTX_VERBOSE")) fprintf(stderr, "[ptx] k_shade blocks per CU: %d\n", per_cu);
+        sc->shade_grid = prop.multiProcessorCount * per_cu;
+    }
     sc->tgrid = prop.multiProcessorCount * PTX_BLOCKS_PER_CU;  // sized so that the LDS of a CU is filled
     sc->flags = flags;
     if (const char* e = getenv("PTX_PIPES")) {
@@ -1277,9 +1326,8 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         st.sh_T = p.sh_T.p;
         st.sh_contrib = p.sh_contrib.p;
         st.sh_occ = p.sh_occ.p;
-        st.ext_counts = p.counts.p;
-        st.sh_counts = p.counts.p + (B + 1);
-        st.cursors = p.counts.p + (2 * B + 1);
+        st.qcounts = p.counts.p;
+        st.cursors = p.counts.p + (2 * B + 2);
         st.totals = sc->totals.p;
         st.cam = *cam;
         st.seed = seed;
@@ -1295,22 +1343,23 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
             {
                 Timed tm(sc, stream, KC_EXTEND);
                 ++sc->extend_launches;
-                rc = launch_traverse<false>(sc, st.rays[(b - 1) & 1], st.ext_counts + (b - 1), 1, 0, st.hits, nullptr,
+                rc = launch_traverse<false>(sc, st.rays[(b - 1) & 1], st.qcounts + 2 * (b - 1), 1, 0, st.hits, nullptr,
                                             st.cursors + 2 * (b - 1), p.spill.p, sc->totals.p + 2, stream);
                 if (rc) return rc;
             }
             {
                 Timed tm(sc, stream, KC_SHADE);
-                if (L == 1) k_shade<1><<<grid, BLOCK, 0, stream>>>(sc->dev, st, b);
-                else if (L == 2) k_shade<2><<<grid, BLOCK, 0, stream>>>(sc->dev, st, b);
-                else if (L == 4) k_shade<4><<<grid, BLOCK, 0, stream>>>(sc->dev, st, b);
-                else k_shade<0><<<grid, BLOCK, 0, stream>>>(sc->dev, st, b);
+                const int sg = sc->shade_grid;
+                if (L == 1) k_shade<1><<<sg, BLOCK, 0, stream>>>(sc->dev, st, b);
+                else if (L == 2) k_shade<2><<<sg, BLOCK, 0, stream>>>(sc->dev, st, b);
+                else if (L == 4) k_shade<4><<<sg, BLOCK, 0, stream>>>(sc->dev, st, b);
+                else k_shade<0><<<sg, BLOCK, 0, stream>>>(sc->dev, st, b);
             }
             if (L > 0) {
                 {
                     Timed tm(sc, stream, KC_SHADOW);
                     ++sc->shadow_launches;
-                    rc = launch_traverse<true>(sc, st.sh_rays, st.sh_counts + (b - 1), L, 0, nullptr, st.sh_occ,
+                    rc = launch_traverse<true>(sc, st.sh_rays, st.qcounts + 2 * b + 1, L, 0, nullptr, st.sh_occ,
                                                st.cursors + 2 * (b - 1) + 1, p.spill.p, sc->totals.p + 4, stream);
                     if (rc) return rc;
                 }
@@ -1378,8 +1427,8 @@ int ptx_last_batch_counts(ptx_scene* sc, uint32_t* ext, uint32_t* sh, uint32_t n
     std::vector<uint32_t> host(4 * (size_t)B + 2);
     HIP_TRY(hipMemcpy(host.data(), sc->pipes[sc->last_pipe]->counts.p, host.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (uint32_t b = 0; b < n; ++b) {
-        ext[b] = b < B ? host[b] : 0;
-        sh[b] = b < B ? host[B + 1 + b] : 0;
+        ext[b] = b < B ? host[2 * b] : 0;
+        sh[b] = b < B ? host[2 * b + 3] : 0;
     }
     return PTX_OK;
 }
