@@ -30,9 +30,6 @@ using namespace ptx;
 
 namespace {
 
-#ifndef PTX_WAVE_SLOTS
-#define PTX_WAVE_SLOTS 0
-#endif
 #ifndef PTX_BLOCK
 #define PTX_BLOCK 256
 #endif
@@ -71,10 +68,18 @@ struct RenderState {
     float4* sh_T;        // [i] {transport before this bounce's update, bits(pid)}
     float4* sh_contrib;  // [i * n_lights + l] {bsdf * emitted * |cos|, 0}
     uint8_t* sh_occ;     // [i * n_lights + l] 1 = occluded
-    // Queue lengths as pairs, so that k_shade bumps both of its output queues with ONE 64-bit atomic:
-    // qcounts[2k] = extend queue of bounce k+1 (k = 0..max_bounces), qcounts[2b+1] = shadow queue of bounce b
-    // (paths; x n_lights rays).
+    // Queues are SEGMENTED: segment s owns slots [s * seg_cap, (s + 1) * seg_cap) of every queue for the
+    // whole batch; k_generate fills the segments in path order, and workgroup s of k_shade / k_resolve reads
+    // segment s and compacts its survivors to the front of segment s of the output queue with a counter of
+    // its own.  No global atomic sits on the path of a queue write (a single hot counter line serialises at
+    // ~12 ns per workgroup: it was what bound k_shade), and the queue order is deterministic.
+    uint32_t* seg_ext[2];  // [n_seg] entries of each segment of the extend queues A/B
+    uint32_t* seg_sh;      // [n_seg] entries of each segment of the shadow queue (paths; x n_lights rays)
+    uint32_t n_seg, seg_cap;
+    // Totals and per-segment maxima per bounce, as pairs: [2k] = extend queue of bounce k+1 (k = 0..max_bounces),
+    // [2b+1] = shadow queue of bounce b.  One atomic add + two atomic max per workgroup and kernel.
     uint32_t* qcounts;
+    uint32_t* qmax;
     uint32_t* cursors;     // [2 * max_bounces] work cursors of the persistent traversal launches
     unsigned long long* totals;  // extend rays, shadow rays, ext inner, ext tris, sh inner, sh tris
     ptx_pinhole cam;
@@ -125,53 +130,32 @@ __device__ inline uint32_t block_slot(bool flag, uint32_t* counter, uint32_t* ld
     return slot;
 }
 
-// The same for two queues at once: one barrier sequence, and ONE 64-bit atomic on the pair of queue
-// counters {low word: queue 0, high word: queue 1}.  The atomic on the (hot, shared by every workgroup)
-// counter address is what bounds k_shade: halving their number took 25 % off the kernel.
-__device__ inline void block_slot2(bool f0, bool f1, unsigned long long* counter_pair, uint32_t* lds /* 2 * WAVES + 2 */,
-                                   uint32_t& slot0, uint32_t& slot1) {
+// Workgroup-wide exclusive prefix of two flags at once (wave ballots + wave totals through LDS).  One barrier:
+// the LDS scratch alternates between two halves, chosen by the caller's iteration parity.
+template <int NW>
+__device__ inline void block_prefix2(bool f0, bool f1, uint32_t* lds /* 2 x 2 x NW */, uint32_t parity, uint32_t& pre0,
+                                     uint32_t& pre1, uint32_t& tot0, uint32_t& tot1) {
     const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const uint32_t before0 = __popcll(b0 & lt), before1 = __popcll(b1 & lt);
+    uint32_t* l = lds + parity * 2u * NW;
     if (lane == 0) {
-        lds[wave] = (uint32_t)__popcll(b0);
-        lds[WAVES + 1 + wave] = (uint32_t)__popcll(b1);
+        l[wave] = (uint32_t)__popcll(b0);
+        l[NW + wave] = (uint32_t)__popcll(b1);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t0 = 0, t1 = 0;
-        for (int w = 0; w < WAVES; ++w) {
-            const uint32_t c0 = lds[w], c1 = lds[WAVES + 1 + w];
-            lds[w] = t0;
-            lds[WAVES + 1 + w] = t1;
-            t0 += c0;
-            t1 += c1;
-        }
-        unsigned long long base = 0ull;
-        if (t0 | t1) base = atomicAdd(counter_pair, (unsigned long long)t0 | ((unsigned long long)t1 << 32));
-        lds[WAVES] = (uint32_t)base;
-        lds[2 * WAVES + 1] = (uint32_t)(base >> 32);
+    uint32_t p0 = 0, p1 = 0, t0 = 0, t1 = 0;
+    for (uint32_t w = 0; w < (uint32_t)NW; ++w) {
+        const uint32_t c0 = l[w], c1 = l[NW + w];
+        p0 += w < wave ? c0 : 0u;
+        p1 += w < wave ? c1 : 0u;
+        t0 += c0;
+        t1 += c1;
     }
-    __syncthreads();
-    slot0 = lds[WAVES] + lds[wave] + before0;
-    slot1 = lds[2 * WAVES + 1] + lds[WAVES + 1 + wave] + before1;
-    __syncthreads();  // lds is reused by the next iteration
-}
-
-// Wave-level variant: no barrier, no LDS; one 64-bit atomic per wave.  Queue order then follows the order
-// in which waves arrive (results do not depend on it: every path owns its state slot).
-__device__ inline void wave_slot2(bool f0, bool f1, unsigned long long* counter_pair, uint32_t& slot0, uint32_t& slot1) {
-    const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);
-    const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    unsigned long long base = 0ull;
-    if (lane == 0 && (b0 | b1))
-        base = atomicAdd(counter_pair, (unsigned long long)__popcll(b0) | ((unsigned long long)__popcll(b1) << 32));
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
-    slot0 = lo + (uint32_t)__popcll(b0 & lt);
-    slot1 = hi + (uint32_t)__popcll(b1 & lt);
+    pre0 = p0 + (uint32_t)__popcll(b0 & lt);
+    pre1 = p1 + (uint32_t)__popcll(b1 & lt);
+    tot0 = t0;
+    tot1 = t1;
 }
 
 __device__ inline void wave_add(unsigned long long* dst, uint32_t v) {
@@ -247,7 +231,11 @@ struct TravArgs {
     const uint32_t* leaf_list; // triangle indices of the multi-triangle leaves, last one flagged
     const TriRec* tris;
     const ptx_ray* rays;
-    const uint32_t* count_ptr;  // device-side ray count (x count_scale), or NULL to use fixed_count
+    // rays [0, fixed_count), or (seg_counts != NULL) the first seg_counts[s] * count_scale rays of every
+    // segment s, segments seg_cap * count_scale rays apart; *max_ptr = the largest seg_counts[s]
+    const uint32_t* seg_counts;
+    const uint32_t* max_ptr;
+    uint32_t n_seg, seg_cap;
     uint32_t count_scale, fixed_count;
     int32_t root;    // descriptor of the root
     ptx_hit* hits;   // nearest-hit output (ANY == false)
@@ -272,17 +260,24 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
     const uint32_t gtid = blockIdx.x * TBLOCK + tid;
     const uint32_t so0 = tid * 8u;                    // this lane's sentinel
     const uint32_t so_last = so0 + LVL * LDS_DEPTH;   // its last LDS level; deeper levels live in a.spill
-    const uint32_t count = a.count_ptr ? *a.count_ptr * a.count_scale : a.fixed_count;
+    const bool segmented = a.seg_counts != nullptr;
+    const uint32_t n_seg = segmented ? a.n_seg : 1u;
+    const uint32_t seg_stride = a.seg_cap * a.count_scale;
+    const uint32_t max_count = segmented ? *a.max_ptr * a.count_scale : a.fixed_count;  // rays of the fullest segment
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int32_t top_n = (int32_t)a.top_n;
     const uint32_t top_base = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint4*)s_top);
     for (uint32_t i = tid; i < a.top_n; i += TBLOCK) s_top[i] = a.nodes[i];
     __syncthreads();
-    // window size: ~4 windows per wave over the launch, 64..512 rays, multiple of 64
-    uint32_t chunk = count / (gridDim.x * (TBLOCK / 64) * 4u);
-    chunk = chunk < 64u ? 64u : (chunk > 512u ? 512u : (chunk & ~63u));
+    // Windows: `chunk` rays of one segment, ~4 per wave over the launch (64..512).  Every segment gets as many
+    // windows as the fullest one needs (segment-major, so neighbouring waves work on neighbouring rays); the
+    // ones past the end of a shorter segment are skipped.
+    const unsigned long long est = (unsigned long long)max_count * n_seg / (gridDim.x * (TBLOCK / 64) * 4u);
+    const uint32_t chunk = est >= 512u ? 512u : (est >= 256u ? 256u : (est >= 128u ? 128u : 64u));
+    const uint32_t wps = (max_count + chunk - 1u) / chunk;  // windows per segment
+    const uint32_t n_windows = wps * n_seg;
     uint32_t lo = 0, hi = 0;
-    bool drained = false;  // the launch's cursor has passed `count`
+    bool drained = false;  // the launch's cursor has passed the last window
     int32_t cur = DESC_IDLE;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, t_end = 0, t1 = 0, t2 = 0;
     uint32_t ridx = 0;
@@ -302,15 +297,19 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
             if (!idle) break;
             if (lo >= hi) {
                 if (drained) break;
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(a.cursor, chunk);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= count) {
+                uint32_t w = 0;
+                if (lane == 0) w = atomicAdd(a.cursor, 1u);
+                w = __builtin_amdgcn_readfirstlane(w);
+                if (w >= n_windows) {
                     drained = true;
                     break;
                 }
-                lo = base;
-                hi = base + chunk < count ? base + chunk : count;
+                const uint32_t seg = w / wps, k = w - seg * wps;
+                const uint32_t cnt = segmented ? a.seg_counts[seg] * a.count_scale : a.fixed_count;
+                const uint32_t first = k * chunk;
+                if (first >= cnt) continue;  // this segment is shorter than the fullest one
+                lo = seg * seg_stride + first;
+                hi = seg * seg_stride + (first + chunk < cnt ? first + chunk : cnt);
             }
             const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
             const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -471,7 +470,16 @@ __global__ __launch_bounds__(BLOCK) void k_generate(RenderState st) {
         st.transport[pid] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
         st.radiance[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) st.qcounts[0] = total;
+    if (blockIdx.x == 0) {  // the first queue fills the segments in path order
+        for (uint32_t sg = threadIdx.x; sg < st.n_seg; sg += BLOCK) {
+            const unsigned long long first = (unsigned long long)sg * st.seg_cap;
+            st.seg_ext[0][sg] = first >= total ? 0u : (total - first < st.seg_cap ? (uint32_t)(total - first) : st.seg_cap);
+        }
+        if (threadIdx.x == 0) {
+            st.qcounts[0] = total;
+            st.qmax[0] = total < st.seg_cap ? total : st.seg_cap;
+        }
+    }
 }
 
 struct Bsdf {
@@ -576,20 +584,26 @@ __device__ inline Bsdf material_sample(const DevMaterial& m, V3 wi, V3 n, float 
 // One bounce of trace_ray (pathtracer.rs:33-108) for every entry of the current extend queue.
 template <int NL /* compile-time light count, 0 = read it from the scene */>
 __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, uint32_t bounce /* 1-based */) {
-    __shared__ uint32_t lds[2 * WAVES + 2];
+    __shared__ uint32_t lds[4 * WAVES];
     const uint32_t q = (bounce - 1u) & 1u;
     const ptx_ray* __restrict__ rays_in = st.rays[q];
     const uint32_t* __restrict__ pid_in = st.pids[q];
     ptx_ray* __restrict__ rays_out = st.rays[q ^ 1u];
     uint32_t* __restrict__ pid_out = st.pids[q ^ 1u];
-    const uint32_t count = st.qcounts[2u * (bounce - 1u)];
     const uint32_t n_lights = NL ? (uint32_t)NL : sc.n_lights;
     const uint32_t base = ptx_dim_base(bounce, n_lights);
     constexpr int MAXL = NL ? NL : PTX_MAX_LIGHTS;
+    uint32_t parity = 0;
 
-    for (uint32_t start = blockIdx.x * BLOCK; start < count; start += gridDim.x * BLOCK) {
-        const uint32_t i = start + threadIdx.x;
-        const bool active = i < count;
+    // one workgroup per queue segment (see RenderState): read segment `seg`, write the survivors to the front
+    // of segment `seg` of the output queues
+    for (uint32_t seg = blockIdx.x; seg < st.n_seg; seg += gridDim.x) {
+    const uint32_t count = st.seg_ext[q][seg];
+    const uint32_t seg_base = seg * st.seg_cap;
+    uint32_t n_next = 0, n_shadow = 0;
+    for (uint32_t start = 0; start < count; start += BLOCK) {
+        const uint32_t i = seg_base + start + threadIdx.x;
+        const bool active = start + threadIdx.x < count;
         bool emit_next = false, emit_shadow = false;
         uint32_t pid = 0;
         V3 next_o = v3(0, 0, 0), next_d = v3(0, 0, 0), point_above = v3(0, 0, 0), T_old = v3(0, 0, 0);
@@ -665,14 +679,13 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, ui
                 }
             }
         }
-        // one compaction pass for both queues: wave ballots, LDS prefix over the waves, ONE atomic per
-        // workgroup and queue
-        uint32_t slot_n, slot_s;
-#if PTX_WAVE_SLOTS
-        wave_slot2(emit_next, emit_shadow, reinterpret_cast<unsigned long long*>(st.qcounts + 2u * bounce), slot_n, slot_s);
-#else
-        block_slot2(emit_next, emit_shadow, reinterpret_cast<unsigned long long*>(st.qcounts + 2u * bounce), lds, slot_n, slot_s);
-#endif
+        // one compaction pass for both queues: wave ballots + LDS prefix over the waves, no atomics
+        uint32_t pre_n, pre_s, tot_n, tot_s;
+        block_prefix2<WAVES>(emit_next, emit_shadow, lds, parity, pre_n, pre_s, tot_n, tot_s);
+        parity ^= 1u;
+        const uint32_t slot_n = seg_base + n_next + pre_n, slot_s = seg_base + n_shadow + pre_s;
+        n_next += tot_n;
+        n_shadow += tot_s;
         if (emit_next) {
             reinterpret_cast<float4*>(rays_out)[2 * (size_t)slot_n] = make_float4(next_o.x, next_o.y, next_o.z, 0.0f);
             reinterpret_cast<float4*>(rays_out)[2 * (size_t)slot_n + 1] =
@@ -692,14 +705,27 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, ui
             }
         }
     }
+    if (threadIdx.x == 0) {
+        st.seg_ext[q ^ 1u][seg] = n_next;
+        st.seg_sh[seg] = n_shadow;
+        if (n_next | n_shadow) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(st.qcounts + 2u * bounce),
+                      (unsigned long long)n_next | ((unsigned long long)n_shadow << 32));
+            atomicMax(st.qmax + 2u * bounce, n_next);
+            atomicMax(st.qmax + 2u * bounce + 1u, n_shadow);
+        }
+    }
+    }
 }
 
 // Next-event estimation resolve: accumulated_radiance += accumulated_transport * sum over lights of the
 // unoccluded contributions, in MTL light order (pathtracer.rs:68-86).  One path per lane; the occlusion
 // flags come from the any-hit traversal launch over the shadow-ray queue.
 __global__ __launch_bounds__(BLOCK) void k_resolve(RenderState st, uint32_t bounce, uint32_t n_lights) {
-    const uint32_t count = st.qcounts[2u * bounce + 1u];
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
+    (void)bounce;
+    for (uint32_t seg = blockIdx.x; seg < st.n_seg; seg += gridDim.x)
+    for (uint32_t k = threadIdx.x, count = st.seg_sh[seg]; k < count; k += BLOCK) {
+        const uint32_t i = seg * st.seg_cap + k;
         const float4 T = st.sh_T[i];
         const uint32_t pid = f2u(T.w);
         if (n_lights == 1u) {  // k_shade<1> stored transport * contribution
@@ -827,6 +853,12 @@ struct ptx_scene {
     // bounces of another.
     struct Pipe {
         hipStream_t stream = nullptr;
+        // the shadow rays of bounce b and the extend rays of bounce b+1 only depend on k_shade(b): they are
+        // traversed concurrently, the shadow launch (and its resolve) on this second stream, so that the
+        // long-ray tail of one launch (~0.3 ms with the GPU mostly idle) is covered by the other
+        hipStream_t stream2 = nullptr;
+        hipEvent_t ev_shade = nullptr, ev_resolve = nullptr;
+        DevBuf<uint2> spill2;
         hipEvent_t ev_accum = nullptr, ev_join = nullptr;
         DevBuf<ptx_ray> rays[2];
         DevBuf<uint32_t> pids[2];
@@ -835,15 +867,19 @@ struct ptx_scene {
         DevBuf<ptx_ray> sh_rays;
         DevBuf<uint8_t> sh_occ;
         DevBuf<uint2> spill;
-        DevBuf<uint32_t> counts;
+        DevBuf<uint32_t> counts, segs;
         ~Pipe() {
             if (ev_accum) (void)hipEventDestroy(ev_accum);
             if (ev_join) (void)hipEventDestroy(ev_join);
+            if (ev_shade) (void)hipEventDestroy(ev_shade);
+            if (ev_resolve) (void)hipEventDestroy(ev_resolve);
+            if (stream2) (void)hipStreamDestroy(stream2);
             if (stream) (void)hipStreamDestroy(stream);
         }
     };
     std::vector<std::unique_ptr<Pipe>> pipes;
     uint32_t n_pipes = 1;
+    bool overlap_shadow = false;  // PTX_OVERLAP=1: shadow(b) and extend(b+1) on two streams (measured: +0.9 %, and it blurs the per-kernel timings)
     int last_pipe = 0;
     hipEvent_t ev_fork = nullptr;
     DevBuf<uint2> spill;  // of the *_batch entry points
@@ -940,6 +976,10 @@ int ensure_render_state(ptx_scene* sc, size_t paths) {
             HIP_TRY(hipEventCreateWithFlags(&up->ev_accum, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&up->ev_join, hipEventDisableTiming));
             HIP_TRY(up->spill.ensure((size_t)(PTX_MAX_DEPTH - LDS_DEPTH) * sc->tgrid * TBLOCK));
+            HIP_TRY(hipStreamCreateWithFlags(&up->stream2, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&up->ev_shade, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&up->ev_resolve, hipEventDisableTiming));
+            HIP_TRY(up->spill2.ensure((size_t)(PTX_MAX_DEPTH - LDS_DEPTH) * sc->tgrid * TBLOCK));
         }
         ptx_scene::Pipe& p = *up;
         for (int q = 0; q < 2; ++q) {
@@ -953,7 +993,8 @@ int ensure_render_state(ptx_scene* sc, size_t paths) {
         HIP_TRY(p.sh_rays.ensure(paths * L));
         HIP_TRY(p.sh_contrib.ensure(paths * L));
         HIP_TRY(p.sh_occ.ensure(paths * L));
-        HIP_TRY(p.counts.ensure(4 * (size_t)B + 2));
+        HIP_TRY(p.counts.ensure(6 * (size_t)B + 4));
+        HIP_TRY(p.segs.ensure(3 * (size_t)sc->shade_grid));
     }
     if (!sc->totals.p) {
         HIP_TRY(sc->totals.ensure(24));
@@ -1044,10 +1085,15 @@ std::string build_device_tree(const ptx_kdnode* in, uint32_t n_nodes, const uint
     return too_big ? "triangle index or leaf list beyond 2^30 - 3" : "";
 }
 
+struct SegRange {  // a segmented queue as the traversal kernel sees it (see RenderState)
+    const uint32_t* counts = nullptr;
+    const uint32_t* max_ptr = nullptr;
+    uint32_t n_seg = 1, cap = 0, scale = 1;
+};
+
 template <bool ANY>
-int launch_traverse(ptx_scene* sc, const ptx_ray* d_rays, const uint32_t* d_count, uint32_t count_scale, uint32_t n,
-                    ptx_hit* d_hits, uint8_t* d_occ, uint32_t* d_cursor, uint2* d_spill, unsigned long long* work,
-                    hipStream_t stream) {
+int launch_traverse(ptx_scene* sc, const ptx_ray* d_rays, const SegRange& sr, uint32_t n, ptx_hit* d_hits, uint8_t* d_occ,
+                    uint32_t* d_cursor, uint2* d_spill, unsigned long long* work, hipStream_t stream) {
     const bool count = (sc->flags & PTX_FLAG_COUNT_WORK) != 0 && work;
     TravArgs a{};
     a.nodes = sc->dev_nodes.p;
@@ -1056,8 +1102,11 @@ int launch_traverse(ptx_scene* sc, const ptx_ray* d_rays, const uint32_t* d_coun
     a.root = sc->root_desc;
     a.tris = sc->dev.tris;
     a.rays = d_rays;
-    a.count_ptr = d_count;
-    a.count_scale = count_scale;
+    a.seg_counts = sr.counts;
+    a.max_ptr = sr.max_ptr;
+    a.n_seg = sr.n_seg;
+    a.seg_cap = sr.cap;
+    a.count_scale = sr.scale;
     a.fixed_count = n;
     a.hits = d_hits;
     a.occ = d_occ;
@@ -1067,7 +1116,7 @@ int launch_traverse(ptx_scene* sc, const ptx_ray* d_rays, const uint32_t* d_coun
     a.work = work;
     a.prof = sc->totals.p + (ANY ? 16 : 8);
     int grid = sc->tgrid;  // the spill area is sized for this many threads: never launch more
-    if (!d_count) {
+    if (!sr.counts) {
         int need = (int)((n + 63) / 64 + (TBLOCK / 64) - 1) / (TBLOCK / 64);
         if (need < grid) grid = need > 0 ? need : 1;
     }
@@ -1128,6 +1177,7 @@ int ptx_scene_create(const ptx_scene_desc* d, uint32_t flags, ptx_scene** out) {
     }
     sc->tgrid = prop.multiProcessorCount * PTX_BLOCKS_PER_CU;  // sized so that the LDS of a CU is filled
     sc->flags = flags;
+    if (const char* e = getenv("PTX_OVERLAP")) sc->overlap_shadow = atoi(e) != 0;
     if (const char* e = getenv("PTX_PIPES")) {
         int k = atoi(e);
         if (k >= 1 && k <= 8) sc->n_pipes = (uint32_t)k;
@@ -1217,7 +1267,7 @@ int ptx_intersect_batch_device(ptx_scene* sc, const ptx_ray* d_rays, size_t n, p
     sc->batch_extend_rays += n;
     ++sc->extend_launches;
     HIP_TRY(hipMemsetAsync(sc->batch_cursor.p, 0, sizeof(uint32_t), (hipStream_t)stream));
-    return launch_traverse<false>(sc, d_rays, nullptr, 1, (uint32_t)n, d_hits, nullptr, sc->batch_cursor.p, sc->spill.p,
+    return launch_traverse<false>(sc, d_rays, SegRange{}, (uint32_t)n, d_hits, nullptr, sc->batch_cursor.p, sc->spill.p,
                                   sc->totals.p + 2, (hipStream_t)stream);
 }
 
@@ -1231,7 +1281,7 @@ int ptx_occluded_batch_device(ptx_scene* sc, const ptx_ray* d_rays, size_t n, ui
     sc->batch_shadow_rays += n;
     ++sc->shadow_launches;
     HIP_TRY(hipMemsetAsync(sc->batch_cursor.p, 0, sizeof(uint32_t), (hipStream_t)stream));
-    return launch_traverse<true>(sc, d_rays, nullptr, 1, (uint32_t)n, nullptr, d_out, sc->batch_cursor.p, sc->spill.p,
+    return launch_traverse<true>(sc, d_rays, SegRange{}, (uint32_t)n, nullptr, d_out, sc->batch_cursor.p, sc->spill.p,
                                  sc->totals.p + 4, (hipStream_t)stream);
 }
 
@@ -1290,7 +1340,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         const uint32_t per_pipe = (sample_count + n_pipes - 1) / n_pipes;
         if (per_pipe > 0 && per_pipe < S) S = per_pipe;
     }
-    while ((uint64_t)S * n_pixels > (1ull << 28)) S = (S + 1) / 2;  // path ids are 32-bit; keep slots < 2^28
+    while ((uint64_t)S * n_pixels > (1ull << 28) - (1ull << 20)) S = (S + 1) / 2;  // queue slots (with segment padding) stay < 2^28
     if (S < 1) S = 1;
     if (sample_count > 0) {  // equal-sized batches, their number a multiple of the pipeline count when possible
         uint32_t n_batches = (sample_count + S - 1) / S;
@@ -1298,7 +1348,13 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         if (n_batches > sample_count) n_batches = sample_count;
         S = (sample_count + n_batches - 1) / n_batches;
     }
-    int rc = ensure_render_state(sc, (size_t)S * n_pixels);
+    // queue segments (see RenderState): one per k_shade workgroup, sized for a full batch
+    const uint64_t batch_paths = (uint64_t)S * n_pixels;
+    uint32_t n_seg = (uint32_t)sc->shade_grid;
+    if ((batch_paths + 255) / 256 < n_seg) n_seg = (uint32_t)((batch_paths + 255) / 256);
+    if (n_seg < 1) n_seg = 1;
+    const uint32_t seg_cap = (uint32_t)(((batch_paths + n_seg - 1) / n_seg + 63) / 64 * 64);
+    int rc = ensure_render_state(sc, (size_t)n_seg * seg_cap);
     if (rc) return rc;
 
     const uint32_t B = sc->dev.max_bounces, L = sc->dev.n_lights;
@@ -1327,46 +1383,76 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         st.sh_contrib = p.sh_contrib.p;
         st.sh_occ = p.sh_occ.p;
         st.qcounts = p.counts.p;
-        st.cursors = p.counts.p + (2 * B + 2);
+        st.qmax = p.counts.p + (2 * B + 2);
+        st.cursors = p.counts.p + (4 * B + 4);
+        st.seg_ext[0] = p.segs.p;
+        st.seg_ext[1] = p.segs.p + n_seg;
+        st.seg_sh = p.segs.p + 2 * (size_t)n_seg;
+        st.n_seg = n_seg;
+        st.seg_cap = seg_cap;
         st.totals = sc->totals.p;
         st.cam = *cam;
         st.seed = seed;
         st.n_pixels = n_pixels;
         st.n_samples = ns;
         st.first_sample = first_sample + done;
-        HIP_TRY(hipMemsetAsync(p.counts.p, 0, (4 * (size_t)B + 2) * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(p.counts.p, 0, (6 * (size_t)B + 4) * sizeof(uint32_t), stream));
         {
             Timed tm(sc, stream, KC_GENERATE);
             k_generate<<<grid, BLOCK, 0, stream>>>(st);
         }
+        const bool overlap = sc->overlap_shadow && L > 0;
+        hipStream_t sstream = overlap ? p.stream2 : stream;  // stream of the shadow launches
+        uint2* sspill = overlap ? p.spill2.p : p.spill.p;
         for (uint32_t b = 1; b <= B; ++b) {
             {
                 Timed tm(sc, stream, KC_EXTEND);
                 ++sc->extend_launches;
-                rc = launch_traverse<false>(sc, st.rays[(b - 1) & 1], st.qcounts + 2 * (b - 1), 1, 0, st.hits, nullptr,
-                                            st.cursors + 2 * (b - 1), p.spill.p, sc->totals.p + 2, stream);
+                SegRange sr;
+                sr.counts = st.seg_ext[(b - 1) & 1];
+                sr.max_ptr = st.qmax + 2 * (b - 1);
+                sr.n_seg = n_seg;
+                sr.cap = seg_cap;
+                rc = launch_traverse<false>(sc, st.rays[(b - 1) & 1], sr, 0, st.hits, nullptr, st.cursors + 2 * (b - 1),
+                                            p.spill.p, sc->totals.p + 2, stream);
                 if (rc) return rc;
             }
+            // k_shade(b) reuses the shadow queue and adds to the radiance: after resolve(b-1)
+            if (overlap && b > 1) HIP_TRY(hipStreamWaitEvent(stream, p.ev_resolve, 0));
             {
                 Timed tm(sc, stream, KC_SHADE);
-                const int sg = sc->shade_grid;
+                const int sg = (int)n_seg;
                 if (L == 1) k_shade<1><<<sg, BLOCK, 0, stream>>>(sc->dev, st, b);
                 else if (L == 2) k_shade<2><<<sg, BLOCK, 0, stream>>>(sc->dev, st, b);
                 else if (L == 4) k_shade<4><<<sg, BLOCK, 0, stream>>>(sc->dev, st, b);
                 else k_shade<0><<<sg, BLOCK, 0, stream>>>(sc->dev, st, b);
             }
             if (L > 0) {
+                if (overlap) {
+                    HIP_TRY(hipEventRecord(p.ev_shade, stream));
+                    HIP_TRY(hipStreamWaitEvent(sstream, p.ev_shade, 0));
+                }
                 {
-                    Timed tm(sc, stream, KC_SHADOW);
+                    Timed tm(sc, sstream, KC_SHADOW);
                     ++sc->shadow_launches;
-                    rc = launch_traverse<true>(sc, st.sh_rays, st.qcounts + 2 * b + 1, L, 0, nullptr, st.sh_occ,
-                                               st.cursors + 2 * (b - 1) + 1, p.spill.p, sc->totals.p + 4, stream);
+                    SegRange sr;
+                    sr.counts = st.seg_sh;
+                    sr.max_ptr = st.qmax + 2 * b + 1;
+                    sr.n_seg = n_seg;
+                    sr.cap = seg_cap;
+                    sr.scale = L;
+                    rc = launch_traverse<true>(sc, st.sh_rays, sr, 0, nullptr, st.sh_occ, st.cursors + 2 * (b - 1) + 1, sspill,
+                                               sc->totals.p + 4, sstream);
                     if (rc) return rc;
                 }
-                Timed tm(sc, stream, KC_OTHER);
-                k_resolve<<<grid, BLOCK, 0, stream>>>(st, b, L);
+                {
+                    Timed tm(sc, sstream, KC_OTHER);
+                    k_resolve<<<(int)n_seg, BLOCK, 0, sstream>>>(st, b, L);
+                }
+                if (overlap) HIP_TRY(hipEventRecord(p.ev_resolve, sstream));
             }
         }
+        if (overlap) HIP_TRY(hipStreamWaitEvent(stream, p.ev_resolve, 0));
         // samples reach a pixel in index order: this batch's accumulate waits for the previous batch's
         if (prev_accum) HIP_TRY(hipStreamWaitEvent(stream, prev_accum, 0));
         {
@@ -1424,7 +1510,7 @@ int ptx_last_batch_counts(ptx_scene* sc, uint32_t* ext, uint32_t* sh, uint32_t n
     const uint32_t B = sc->cap_bounces;
     if (sc->pipes.empty() || B == 0) return fail(PTX_E_ARG, "ptx_last_batch_counts: nothing rendered yet");
     HIP_TRY(hipDeviceSynchronize());
-    std::vector<uint32_t> host(4 * (size_t)B + 2);
+    std::vector<uint32_t> host(2 * (size_t)B + 4);
     HIP_TRY(hipMemcpy(host.data(), sc->pipes[sc->last_pipe]->counts.p, host.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (uint32_t b = 0; b < n; ++b) {
         ext[b] = b < B ? host[2 * b] : 0;
