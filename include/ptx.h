@@ -145,6 +145,31 @@ int ptx_kdtree_view(const ptx_kdtree* tree, const ptx_kdnode** nodes, uint32_t* 
                     const uint32_t** leaf_indices, uint32_t* n_leaf_indices);
 void ptx_kdtree_free(ptx_kdtree* tree);
 
+/* Tree interchange and statistics.  Text is malloc'ed: release with ptx_free.
+ * ptx_kdtree_write_json = `write_tree_json` (kdtree/src/format.rs:116-130): one line
+ *   {"triangles": [[[x, y, z], [..], [..]], ..], "root": NODE}  with NODE = [i, j, ..] for a leaf or
+ *   {"axis": "X", "distance": d, "left": NODE, "right": NODE}; numbers exactly as Rust prints them.
+ * ptx_kdtree_read_json parses that format (e.g. a tree dumped by the reference's `kdtree-cli -j`) into the
+ *   flattened layout; the triangles come back as 9 floats each (release with ptx_free).
+ * ptx_kdtree_write_pretty = `write_node_pretty` (format.rs:22-47), kdtree-cli's default output.
+ * ptx_kdtree_stats = `statistics` + `tree_cost` of kdtree-cli (kdtree-cli/src/main.rs:45-159). */
+typedef struct ptx_tree_stats {
+    float sah_cost;
+    uint64_t geometries, node_count /* inner nodes + leaves */, leaf_count;
+    uint64_t leaf_depth_min, leaf_depth_max, leaf_depth_total; /* the root has depth 1 */
+    float leaf_depth_mean, leaf_depth_median;
+    uint64_t leaf_geometries_min, leaf_geometries_max, leaf_geometries_total;
+    float leaf_geometries_mean, leaf_geometries_median;
+} ptx_tree_stats;
+int ptx_kdtree_write_json(const float* triangles, uint32_t n_triangles, const ptx_kdnode* nodes, uint32_t n_nodes,
+                          const uint32_t* leaf_indices, uint32_t n_leaf_indices, char** text_out, size_t* len_out);
+int ptx_kdtree_read_json(const char* text, size_t len, ptx_kdtree** tree_out, float** triangles_out,
+                         uint32_t* n_triangles_out);
+int ptx_kdtree_write_pretty(const ptx_kdnode* nodes, uint32_t n_nodes, const uint32_t* leaf_indices,
+                            uint32_t n_leaf_indices, char** text_out, size_t* len_out);
+int ptx_kdtree_stats(const float* triangles, uint32_t n_triangles, const ptx_kdnode* nodes, uint32_t n_nodes,
+                     const uint32_t* leaf_indices, uint32_t n_leaf_indices, const ptx_sah_cost* sah, ptx_tree_stats* out);
+
 /* `KdNode::intersect` for ONE ray on the host, over the flattened tree — the scalar form of the accel
  * seam (kdtree/src/lib.rs:73-132), for callers that need an occasional query without a GPU round trip. */
 int ptx_kdtree_intersect_host(const float* triangles, uint32_t n_triangles, const ptx_kdnode* nodes,

@@ -376,3 +376,129 @@ class Scene:
         rays = np.zeros(cap, RAY_DTYPE)
         n = lib().orc_bounce_rays(self.h, w, h, bounces, C.c_uint64(seed), _p(rays), C.c_size_t(cap), C.byref(fails), threads)
         return rays[:n].copy(), int(fails.value)
+
+
+# ---- kdtree/src/format.rs and kdtree-cli statistics, restated over the oracle's own tree -------
+# Formatting follows Rust's float printing: `{}` = shortest round-trip digits, positional; `{:?}` = the same
+# with at least ".0", scientific outside [1e-4, 1e16) (core::fmt::float).  numpy's Dragon4 "unique" mode gives
+# the same shortest digits independently of the product's std::to_chars.  Parity unpinned: format.rs has no
+# tests of its own; the two implementations pin each other and the hand-written cases in tests/.
+def rust_display_f32(x):
+    x = np.float32(x)
+    if np.isnan(x):
+        return "NaN"
+    if np.isinf(x):
+        return "-inf" if x < 0 else "inf"
+    return np.format_float_positional(x, unique=True, trim="-")
+
+
+def rust_debug_f32(x):
+    x = np.float32(x)
+    if np.isnan(x) or np.isinf(x):
+        return rust_display_f32(x)
+    a = abs(float(x))
+    if a != 0.0 and (a < float(np.float32(1e-4)) or a >= 1e16):
+        return np.format_float_scientific(x, unique=True, trim="-", exp_digits=1).replace("e+", "e")
+    return np.format_float_positional(x, unique=True, trim="0")
+
+
+def any_triangle_arrays(tri9):
+    """`AnyTriangle::from` then `as_arrays()` (any_triangle.rs:9-16, triangle.rs:59-77, axial_triangle.rs:43-49)."""
+    t = np.array(tri9, np.float32).reshape(3, 3)
+    for axis in range(3):
+        if t[0, axis] == t[1, axis] and t[1, axis] == t[2, axis]:
+            t[1, axis] = t[2, axis] = t[0, axis]
+            break
+    return t
+
+
+def tree_json(triangles, nodes, leaves):
+    """`write_tree_json` (format.rs:116-130) over the flattened arrays of Tree.to_flat()."""
+    tri_txt = ", ".join("[" + ", ".join("[" + ", ".join(rust_debug_f32(c) for c in v) + "]" for v in any_triangle_arrays(t)) + "]"
+                        for t in np.asarray(triangles, np.float32).reshape(-1, 9))
+    w0, w1 = nodes["w0"], nodes["w1"]
+    out = []
+    todo = [("node", 0)]  # explicit stack: emit text pieces in preorder
+    while todo:
+        kind, i = todo.pop()
+        if kind == "text":
+            out.append(i)
+            continue
+        if w1[i] & 3 == 3:
+            cnt, off = int(w1[i] >> 2), int(w0[i])
+            out.append("[" + ", ".join(str(int(k)) for k in leaves[off:off + cnt]) + "]")
+            continue
+        dist = np.array([w0[i]], np.uint32).view(np.float32)[0]
+        out.append('{"axis": "%s", "distance": %s, "left": ' % ("XYZ"[int(w1[i] & 3)], rust_display_f32(dist)))
+        todo += [("text", "}"), ("node", int(w1[i] >> 2)), ("text", ', "right": '), ("node", i + 1)]
+    return '{"triangles": [' + tri_txt + '], "root": ' + "".join(out) + "}\n"
+
+
+def tree_pretty(nodes, leaves):
+    """`write_node_pretty` (format.rs:22-47): right subtree is printed before the left one (LIFO)."""
+    w0, w1 = nodes["w0"], nodes["w1"]
+    out, stack = [], [(0, 0)]
+    while stack:
+        depth, i = stack.pop()
+        if w1[i] & 3 == 3:
+            cnt, off = int(w1[i] >> 2), int(w0[i])
+            out.append("  " * depth + "Leaf [" + ", ".join(str(int(k)) for k in leaves[off:off + cnt]) + "]\n")
+        else:
+            stack.append((depth + 1, i + 1))
+            stack.append((depth + 1, int(w1[i] >> 2)))
+            dist = np.array([w0[i]], np.uint32).view(np.float32)[0]
+            out.append("  " * depth + "Split %s %s\n" % ("XYZ"[int(w1[i] & 3)], rust_display_f32(dist)))
+    return "".join(out)
+
+
+def tree_statistics(triangles, nodes, leaves, sah=(1.0, 1.5, 0.8)):
+    """`statistics` (kdtree-cli/src/main.rs:142-159), `Statistics::compute` (:113-133), `tree_cost` (:45-103)."""
+    f = np.float32
+    w0, w1 = nodes["w0"], nodes["w1"]
+    tris = np.stack([any_triangle_arrays(t) for t in np.asarray(triangles, np.float32).reshape(-1, 9)]) if len(triangles) else np.zeros((0, 3, 3), np.float32)
+    lo, hi = (tris.min((0, 1)), tris.max((0, 1))) if len(tris) else (np.zeros(3, f), np.zeros(3, f))
+
+    def area(a, b):
+        s = (b - a).astype(f)
+        return f(2.0) * f(f(f(s[0] * s[1]) + f(s[0] * s[2])) + f(s[1] * s[2]))
+
+    ct, ci, ef = (f(x) for x in sah)
+    scene_area = area(lo, hi)
+    is_empty = lambda i: (w1[i] & 3 == 3) and (w1[i] >> 2) == 0
+
+    def cost(i, a, b):
+        if w1[i] & 3 == 3:
+            return f(f(f(ci * f(int(w1[i] >> 2))) * area(a, b)) / scene_area)
+        split_cost = f(area(a, b) / scene_area)
+        axis, dist = int(w1[i] & 3), np.array([w0[i]], np.uint32).view(f)[0]
+        l, r = i + 1, int(w1[i] >> 2)
+        lb, ra = b.copy(), a.copy()
+        lb[axis] = dist
+        ra[axis] = dist
+        lc, rc = cost(l, a, lb), cost(r, ra, b)
+        node = f(f(f(ct + split_cost) + lc) + rc)
+        return f((ef if (is_empty(l) or is_empty(r)) else f(1.0)) * node)
+
+    import sys
+    sys.setrecursionlimit(max(sys.getrecursionlimit(), 10000))
+    depths, sizes, n_nodes, stack = [], [], 0, [(1, 0)]
+    while stack:
+        d, i = stack.pop()
+        n_nodes += 1
+        if w1[i] & 3 == 3:
+            depths.append(d)
+            sizes.append(int(w1[i] >> 2))
+        else:
+            stack += [(d + 1, i + 1), (d + 1, int(w1[i] >> 2))]
+
+    def compute(v):
+        v = sorted(v)
+        n = len(v)
+        median = f(v[0]) if n == 1 else (f(v[n // 2]) if n % 2 == 0 else f(f(v[n // 2] + v[n // 2 + 1]) / f(2.0)))
+        total = f(0.0)
+        for x in v:
+            total = f(total + f(x))
+        return dict(min=v[0], max=v[-1], total=sum(v), median=median, mean=f(total / f(n)))
+
+    return dict(sah_cost=cost(0, lo.astype(f), hi.astype(f)), geometries=len(tris), node_count=n_nodes, leaf_count=len(depths),
+                leaf_depth=compute(depths), leaf_geometries=compute(sizes))

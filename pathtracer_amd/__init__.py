@@ -162,6 +162,61 @@ class KdTree:
         """Intersect-only device scene (the accel seam without shading data)."""
         return DeviceScene.from_arrays(self.triangles, self.nodes, self.leaf_indices, flags=flags)
 
+    def _text(self, fn, *head):
+        out, n = C.c_void_p(), C.c_size_t()
+        _check(fn(*head, _ptr(self.nodes), len(self.nodes), _ptr(self.leaf_indices), len(self.leaf_indices), C.byref(out), C.byref(n)))
+        try:
+            return C.string_at(out, n.value).decode()
+        finally:
+            lib().ptx_free(out)
+
+    def to_json(self):
+        """`write_tree_json` (kdtree/src/format.rs:116-130): what `kdtree-cli -j` prints."""
+        return self._text(lib().ptx_kdtree_write_json, _ptr(self.triangles), len(self.triangles))
+
+    def pretty(self):
+        """`write_node_pretty` (kdtree/src/format.rs:22-47): kdtree-cli's default dump."""
+        return self._text(lib().ptx_kdtree_write_pretty)
+
+    def stats(self, sah=None):
+        """`statistics` + `tree_cost` of kdtree-cli (kdtree-cli/src/main.rs:45-159)."""
+        sah = sah or SahCost()
+        st = TreeStats()
+        _check(lib().ptx_kdtree_stats(_ptr(self.triangles), len(self.triangles), _ptr(self.nodes), len(self.nodes),
+                                      _ptr(self.leaf_indices), len(self.leaf_indices), C.byref(sah), C.byref(st)))
+        return {k: getattr(st, k) for k, _ in TreeStats._fields_}
+
+    @classmethod
+    def from_json(cls, text):
+        """Reads the reference's JSON tree dump into the flattened layout."""
+        raw = text.encode() if isinstance(text, str) else bytes(text)
+        h, tp, nt = C.c_void_p(), C.c_void_p(), C.c_uint32()
+        _check(lib().ptx_kdtree_read_json(raw, C.c_size_t(len(raw)), C.byref(h), C.byref(tp), C.byref(nt)))
+        try:
+            tris = np.frombuffer(C.string_at(tp, nt.value * 36), np.float32).copy().reshape(-1, 9) if nt.value else np.zeros((0, 9), np.float32)
+            nodes, leaf = _view_tree(h)
+        finally:
+            lib().ptx_kdtree_free(h)
+            lib().ptx_free(tp)
+        return cls(tris, nodes, leaf)
+
+
+class TreeStats(C.Structure):
+    _fields_ = [("sah_cost", C.c_float), ("geometries", C.c_uint64), ("node_count", C.c_uint64), ("leaf_count", C.c_uint64),
+                ("leaf_depth_min", C.c_uint64), ("leaf_depth_max", C.c_uint64), ("leaf_depth_total", C.c_uint64),
+                ("leaf_depth_mean", C.c_float), ("leaf_depth_median", C.c_float),
+                ("leaf_geometries_min", C.c_uint64), ("leaf_geometries_max", C.c_uint64), ("leaf_geometries_total", C.c_uint64),
+                ("leaf_geometries_mean", C.c_float), ("leaf_geometries_median", C.c_float)]
+
+
+def _view_tree(h):
+    pn, pl = C.c_void_p(), C.c_void_p()
+    nn, nl = C.c_uint32(), C.c_uint32()
+    _check(lib().ptx_kdtree_view(h, C.byref(pn), C.byref(nn), C.byref(pl), C.byref(nl)))
+    nodes = np.frombuffer(C.string_at(pn, nn.value * 8), NODE_DTYPE).copy()
+    leaf = np.frombuffer(C.string_at(pl, nl.value * 4), np.uint32).copy() if nl.value else np.zeros(0, np.uint32)
+    return nodes, leaf
+
 
 def build_kdtree(triangles, sah=None):
     """`build_kdtree(&[impl Geometry], &SahCost) -> KdNode` (kdtree/src/build.rs:33-41) on the host."""
@@ -170,11 +225,7 @@ def build_kdtree(triangles, sah=None):
     h = C.c_void_p()
     _check(lib().ptx_kdtree_build(_ptr(t), len(t), C.byref(sah), C.byref(h)))
     try:
-        pn, pl = C.c_void_p(), C.c_void_p()
-        nn, nl = C.c_uint32(), C.c_uint32()
-        _check(lib().ptx_kdtree_view(h, C.byref(pn), C.byref(nn), C.byref(pl), C.byref(nl)))
-        nodes = np.frombuffer(C.string_at(pn, nn.value * 8), NODE_DTYPE).copy()
-        leaf = np.frombuffer(C.string_at(pl, nl.value * 4), np.uint32).copy() if nl.value else np.zeros(0, np.uint32)
+        nodes, leaf = _view_tree(h)
     finally:
         lib().ptx_kdtree_free(h)
     return KdTree(t, nodes, leaf)

@@ -21,6 +21,9 @@ void build_flat_kdtree(const float* tris, uint32_t n, const ptx_sah_cost& sah,
 std::string validate_flat_tree(const ptx_kdnode* nodes, uint32_t n_nodes, const uint32_t* leaf_indices,
                                uint32_t n_leaf_indices, uint32_t n_triangles);
 
+// Wraps arrays into the handle of ptx_kdtree_build / ptx_kdtree_view (host_scene.cpp owns the type).
+ptx_kdtree* kdtree_from_arrays(std::vector<ptx_kdnode>&& nodes, std::vector<uint32_t>&& leaves);
+
 // Device triangle record, 48 bytes = three 16-byte loads.
 //   kind 3 (general, Möller–Trumbore):  f[0..2]=v0  f[3..5]=e1=v1-v0  f[6..8]=e2=v2-v0
 //   kind 0/1/2 (axis-aligned on X/Y/Z): f[0]=plane distance  f[1..2]=v0'  f[3..4]=b1=v1'-v0'

@@ -265,6 +265,15 @@ struct ptx_kdtree {
     std::vector<uint32_t> leaves;
 };
 
+namespace ptx {
+ptx_kdtree* kdtree_from_arrays(std::vector<ptx_kdnode>&& nodes, std::vector<uint32_t>&& leaves) {
+    auto t = std::make_unique<ptx_kdtree>();
+    t->nodes = std::move(nodes);
+    t->leaves = std::move(leaves);
+    return t.release();
+}
+}  // namespace ptx
+
 using namespace ptx;
 
 extern "C" {
