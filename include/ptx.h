@@ -251,11 +251,12 @@ int ptx_last_batch_counts(ptx_scene* scene, uint32_t* extend_counts, uint32_t* s
 int ptx_stats(ptx_scene* scene, ptx_counters* out);
 int ptx_stats_reset(ptx_scene* scene);
 /* Diagnostic (scenes created with PTX_FLAG_COUNT_WORK; no counterpart in the reference): how the lanes of
- * the traversal kernels spent their loop iterations since the last reset.  out16[0..7] = extend,
- * out16[8..15] = shadow: wave iterations, lane-visits of the node step, wave iterations that ran the
+ * the traversal kernels spent their loop iterations since the last reset.  out24[0..11] = extend,
+ * out24[12..23] = shadow: wave iterations, lane-visits of the node step, wave iterations that ran the
  * triangle step, lane-visits of it, wave iterations that ran the leaf-exit step, lane-visits of it,
- * refill rounds, live lane-iterations. */
-int ptx_debug_loop_profile(ptx_scene* scene, uint64_t* out16);
+ * refill rounds, live lane-iterations, then the wave clock (s_memtime ticks, summed over waves) spent in the
+ * refill, node, triangle and leaf-exit parts of the loop. */
+int ptx_debug_loop_profile(ptx_scene* scene, uint64_t* out24);
 
 #ifdef __cplusplus
 }

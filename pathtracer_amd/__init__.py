@@ -410,10 +410,11 @@ class DeviceScene:
 
     def loop_profile(self):
         """Diagnostic (FLAG_COUNT_WORK scenes): lane occupancy of the traversal loop, per kernel."""
-        raw = np.zeros(16, np.uint64)
+        raw = np.zeros(24, np.uint64)
         _check(lib().ptx_debug_loop_profile(self._h, _ptr(raw)))
-        keys = ("iters", "walk_lanes", "tri_iters", "tri_lanes", "end_iters", "end_lanes", "refills", "live_lanes")
-        return {"extend": dict(zip(keys, (int(x) for x in raw[:8]))), "shadow": dict(zip(keys, (int(x) for x in raw[8:])))}
+        keys = ("iters", "walk_lanes", "tri_iters", "tri_lanes", "end_iters", "end_lanes", "refills", "live_lanes",
+                "clk_refill", "clk_node", "clk_tri", "clk_exit")
+        return {"extend": dict(zip(keys, (int(x) for x in raw[:12]))), "shadow": dict(zip(keys, (int(x) for x in raw[12:])))}
 
 
 def to_rgb8(accum, iterations):

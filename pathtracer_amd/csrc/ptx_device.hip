@@ -244,7 +244,7 @@ struct TravArgs {
     uint2* spill;      // [(PTX_MAX_DEPTH - LDS_DEPTH) * spill_stride]
     uint32_t spill_stride;
     unsigned long long* work;  // [2] inner nodes, triangle tests (COUNT)
-    unsigned long long* prof;  // [8] loop profile (COUNT): see ptx_debug_loop_profile
+    unsigned long long* prof;  // [12] loop profile (COUNT): see ptx_debug_loop_profile
 };
 
 template <bool ANY, bool COUNT>
@@ -286,6 +286,14 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
     float bt = 0.0f, bu = 0.0f, bv = 0.0f;  // stay 0 while bi == PTX_MISS
     uint32_t n_inner = 0, n_tris = 0;
     uint32_t pf_iter = 0, pf_walk = 0, pf_tri_iter = 0, pf_tri = 0, pf_end_iter = 0, pf_end = 0, pf_refill = 0, pf_live = 0;
+    uint32_t ck_refill = 0, ck_node = 0, ck_tri = 0, ck_exit = 0;  // wave clock spent in each part (COUNT)
+    long long ck = COUNT ? clock64() : 0;
+#define PTX_CLOCK(acc)                               \
+    if (COUNT) {                                     \
+        const long long now = clock64();             \
+        acc += lane == 0 ? (uint32_t)(now - ck) : 0u; \
+        ck = now;                                    \
+    }
 #define PTX_SLOT(off) (*reinterpret_cast<uint2*>(s_base + (off)))
 #define PTX_SPILL(off) a.spill[(size_t)(((off) - so_last) / LVL - 1u) * a.spill_stride + gtid]
 
@@ -329,6 +337,7 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
             lo += n_idle < avail ? n_idle : avail;
         }
         if (__ballot(cur != DESC_IDLE) == 0ull) break;
+        PTX_CLOCK(ck_refill)
 
         // ---- step the live lanes until enough of them have finished to make a refill worthwhile
         for (;;) {
@@ -367,6 +376,7 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                 }
                 cur = (int32_t)next;
             }
+            PTX_CLOCK(ck_node)
             const unsigned long long in_leaf = __ballot(cur < -2);
             const unsigned long long can_walk = __ballot(cur >= 0);
             if (in_leaf && ((uint32_t)__popcll(in_leaf) >= (ANY ? TRI_BATCH_ANYHIT : TRI_BATCH_NEAREST) || !can_walk)) {
@@ -396,6 +406,7 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                     cur = (last || (ANY && accept)) ? DESC_EXIT : cur + 1;
                 }
             }
+            PTX_CLOCK(ck_tri)
             if (COUNT && __any(cur == DESC_EXIT)) pf_end_iter += lane == 0 ? 1u : 0u;
             if (cur == DESC_EXIT) {  // leaving a leaf: kdtree/src/lib.rs:95-103
                 if (COUNT) ++pf_end;
@@ -425,11 +436,13 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                 t2 = done ? t2 : u2f(tb);
                 so = done ? so : st;
             }
+            PTX_CLOCK(ck_exit)
             const uint32_t live = (uint32_t)__popcll(__ballot(cur != DESC_IDLE));
             if (live == 0) break;
             if (!(drained && lo >= hi) && live <= 64u - REFILL_IDLE) break;
         }
     }
+#undef PTX_CLOCK
 #undef PTX_SLOT
 #undef PTX_SPILL
     if (COUNT) {
@@ -443,6 +456,10 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
         wave_add(&a.prof[5], pf_end);
         wave_add(&a.prof[6], pf_refill);
         wave_add(&a.prof[7], pf_live);
+        wave_add(&a.prof[8], ck_refill);
+        wave_add(&a.prof[9], ck_node);
+        wave_add(&a.prof[10], ck_tri);
+        wave_add(&a.prof[11], ck_exit);
     }
 }
 
@@ -997,8 +1014,8 @@ int ensure_render_state(ptx_scene* sc, size_t paths) {
         HIP_TRY(p.segs.ensure(3 * (size_t)sc->shade_grid));
     }
     if (!sc->totals.p) {
-        HIP_TRY(sc->totals.ensure(24));
-        HIP_TRY(hipMemset(sc->totals.p, 0, 24 * sizeof(unsigned long long)));
+        HIP_TRY(sc->totals.ensure(32));
+        HIP_TRY(hipMemset(sc->totals.p, 0, 32 * sizeof(unsigned long long)));
     }
     sc->cap_paths = paths > sc->cap_paths ? paths : sc->cap_paths;
     sc->cap_lights = L > sc->cap_lights ? L : sc->cap_lights;
@@ -1114,7 +1131,7 @@ int launch_traverse(ptx_scene* sc, const ptx_ray* d_rays, const SegRange& sr, ui
     a.spill = d_spill;
     a.spill_stride = (uint32_t)sc->tgrid * TBLOCK;
     a.work = work;
-    a.prof = sc->totals.p + (ANY ? 16 : 8);
+    a.prof = sc->totals.p + (ANY ? 20 : 8);
     int grid = sc->tgrid;  // the spill area is sized for this many threads: never launch more
     if (!sr.counts) {
         int need = (int)((n + 63) / 64 + (TBLOCK / 64) - 1) / (TBLOCK / 64);
@@ -1242,8 +1259,8 @@ int ptx_scene_create(const ptx_scene_desc* d, uint32_t flags, ptx_scene** out) {
     for (uint32_t l = 0; l < d->n_lights; ++l) sc->dev.lights[l] = d->lights[l];
     memcpy(sc->dev.env, d->environment, sizeof sc->dev.env);
     sc->dev.max_bounces = d->max_bounces;
-    HIP_TRY(sc->totals.ensure(24));
-    HIP_TRY(hipMemset(sc->totals.p, 0, 24 * sizeof(unsigned long long)));
+    HIP_TRY(sc->totals.ensure(32));
+    HIP_TRY(hipMemset(sc->totals.p, 0, 32 * sizeof(unsigned long long)));
     HIP_TRY(sc->spill.ensure((size_t)(PTX_MAX_DEPTH - LDS_DEPTH) * sc->tgrid * TBLOCK));
     HIP_TRY(sc->batch_cursor.ensure(1));
     *out = sc.release();
@@ -1330,17 +1347,18 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
     const uint32_t n_pixels = (uint32_t)n_pixels64;
     // Batch size: large batches amortise the long-ray tail of every launch (measured at 1080^2: 5 -> 64 ->
     // 128 -> 192 samples per batch raises the traversal kernels from 2.5 to ~7 / 11.2 / 11.6 Grays/s).  ~230 B
-    // of queue state per path: the default budget of 240 Mi paths in flight is ~58 GB of the 288 GB of HBM.
+    // of queue state per path: the default budget of 320 Mi paths in flight is ~77 GB of the 288 GB of HBM.
     // With more than one pipeline (ptx_set_pipelines) the batches of a call are spread evenly over them.
     const uint32_t n_pipes = sc->n_pipes;
     uint32_t S = sc->batch_samples;
     if (S == 0) {
-        const uint64_t budget = (240ull << 20) / ((uint64_t)n_pipes * n_pixels);
+        const uint64_t budget = (320ull << 20) / ((uint64_t)n_pipes * n_pixels);
         S = (uint32_t)(budget < 1 ? 1 : (budget > 256 ? 256 : budget));
         const uint32_t per_pipe = (sample_count + n_pipes - 1) / n_pipes;
         if (per_pipe > 0 && per_pipe < S) S = per_pipe;
     }
-    while ((uint64_t)S * n_pixels > (1ull << 28) - (1ull << 20)) S = (S + 1) / 2;  // queue slots (with segment padding) stay < 2^28
+    // queue slots (with segment padding) stay < 2^29, so that slot * n_lights + light (<= 8 lights) fits 32 bits
+    while ((uint64_t)S * n_pixels > (1ull << 29) - (1ull << 20)) S = (S + 1) / 2;
     if (S < 1) S = 1;
     if (sample_count > 0) {  // equal-sized batches, their number a multiple of the pipeline count when possible
         uint32_t n_batches = (sample_count + S - 1) / S;
@@ -1546,13 +1564,13 @@ int ptx_stats(ptx_scene* sc, ptx_counters* out) {
     return PTX_OK;
 }
 
-int ptx_debug_loop_profile(ptx_scene* sc, uint64_t* out16) {
+int ptx_debug_loop_profile(ptx_scene* sc, uint64_t* out24) {
     int rc = check_scene(sc, "ptx_debug_loop_profile");
     if (rc) return rc;
-    if (!out16) return fail(PTX_E_ARG, "ptx_debug_loop_profile: null argument");
+    if (!out24) return fail(PTX_E_ARG, "ptx_debug_loop_profile: null argument");
     HIP_TRY(hipDeviceSynchronize());
     static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "");
-    HIP_TRY(hipMemcpy(out16, sc->totals.p + 8, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out24, sc->totals.p + 8, 24 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return PTX_OK;
 }
 
@@ -1561,7 +1579,7 @@ int ptx_stats_reset(ptx_scene* sc) {
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     resolve_stamps(sc);
-    HIP_TRY(hipMemset(sc->totals.p, 0, 24 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(sc->totals.p, 0, 32 * sizeof(unsigned long long)));
     for (double& v : sc->class_ms) v = 0;
     sc->total_ms = 0;
     sc->samples_done = 0;

@@ -25,3 +25,6 @@ for k, rays, inner, tris in (("extend", st["extend_rays"], st["extend_inner_node
     print("   tri step : ran in %.1f%% of iterations, lanes active %.1f/64" % (100 * p["tri_iters"] / it, p["tri_lanes"] / max(p["tri_iters"], 1)))
     print("   leaf exit: ran in %.1f%% of iterations, lanes active %.1f/64" % (100 * p["end_iters"] / it, p["end_lanes"] / max(p["end_iters"], 1)))
     print("   refill rounds per 100 iterations %.1f" % (100 * p["refills"] / it))
+    clk = sum(p[k] for k in ("clk_refill", "clk_node", "clk_tri", "clk_exit")) or 1
+    print("   wave clock: refill %.1f%%  node step %.1f%%  triangle step %.1f%%  leaf exit %.1f%%   (%.0f ticks per iteration)" % (
+        100 * p["clk_refill"] / clk, 100 * p["clk_node"] / clk, 100 * p["clk_tri"] / clk, 100 * p["clk_exit"] / clk, clk / it))
