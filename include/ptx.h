@@ -240,13 +240,18 @@ int ptx_render_device(ptx_scene* scene, const ptx_pinhole* camera, uint64_t seed
                       uint32_t sample_count, float* d_accum, void* stream);
 /* Samples kept in flight per launch batch (default chosen from the image size). */
 int ptx_set_batch_samples(ptx_scene* scene, uint32_t samples_per_batch);
+/* Queue slots (paths in flight) over all pipelines; 0 = default (320 Mi, ~67 GB).  A batch with more paths
+ * than slots is rendered with path regeneration: finished paths are replaced by the next camera rays of the
+ * batch, so the memory stays bounded while every launch stays wide.  Results do not depend on it. */
+int ptx_set_queue_slots(ptx_scene* scene, uint64_t slots);
 /* Sample batches rendered concurrently, each on a HIP stream of its own (1..8, default 2 or the
  * PTX_PIPES environment variable).  With 1 every kernel has the GPU to itself, which is what a
  * per-kernel measurement wants; results do not depend on it.  No counterpart in the reference. */
 int ptx_set_pipelines(ptx_scene* scene, uint32_t pipelines);
 
-/* Queue lengths of the most recent render batch: extend_counts[b] / shadow_counts[b] = rays of bounce b+1
- * (shadow counts are paths; multiply by the number of lights).  n = capacity of each array. */
+/* Queue lengths of the most recent render batch: extend_counts[r] / shadow_counts[r] = entries of round r+1
+ * (one round = extend + shade + shadow over everything in flight; without path regeneration round r is
+ * bounce r; shadow counts are paths: multiply by the number of lights).  n = capacity of each array. */
 int ptx_last_batch_counts(ptx_scene* scene, uint32_t* extend_counts, uint32_t* shadow_counts, uint32_t n);
 int ptx_stats(ptx_scene* scene, ptx_counters* out);
 int ptx_stats_reset(ptx_scene* scene);

@@ -377,6 +377,9 @@ class DeviceScene:
     def set_batch_samples(self, n):
         _check(lib().ptx_set_batch_samples(self._h, n))
 
+    def set_queue_slots(self, slots):
+        _check(lib().ptx_set_queue_slots(self._h, C.c_uint64(slots)))
+
     def set_pipelines(self, n):
         _check(lib().ptx_set_pipelines(self._h, n))
 
@@ -400,10 +403,11 @@ class DeviceScene:
         return c.as_dict()
 
     def last_batch_counts(self):
-        n = max(self.max_bounces, 1)
+        n = 8 * max(self.max_bounces, 1)  # rounds: up to 8 slot-loads of paths per batch
         e, s = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
         _check(lib().ptx_last_batch_counts(self._h, _ptr(e), _ptr(s), n))
-        return e, s
+        used = max(int(np.nonzero(e)[0].max()) + 1 if e.any() else 1, 1)
+        return e[:used], s[:used]
 
     def stats_reset(self):
         _check(lib().ptx_stats_reset(self._h))

@@ -60,7 +60,6 @@ struct DevScene {
 
 struct RenderState {
     ptx_ray* rays[2];
-    uint32_t* pids[2];
     ptx_hit* hits;
     float4* transport;
     float4* radiance;
@@ -76,8 +75,15 @@ struct RenderState {
     uint32_t* seg_ext[2];  // [n_seg] entries of each segment of the extend queues A/B
     uint32_t* seg_sh;      // [n_seg] entries of each segment of the shadow queue (paths; x n_lights rays)
     uint32_t n_seg, seg_cap;
-    // Totals and per-segment maxima per bounce, as pairs: [2k] = extend queue of bounce k+1 (k = 0..max_bounces),
-    // [2b+1] = shadow queue of bounce b.  One atomic add + two atomic max per workgroup and kernel.
+    // Path regeneration: segment s is responsible for the paths [s * seg_range, (s + 1) * seg_range) of the
+    // batch (path id = sample * n_pixels + pixel) but holds only seg_cap of them at a time; seg_next[s] paths
+    // of its range have been started so far, and k_shade tops the segment up with fresh camera rays as paths
+    // end.  Every launch of a long batch therefore stays wide, whatever the depth of the individual paths.
+    // Queue entries carry their own path id and bounce number ({o, bits(path id)}, {d, bits(bounce)}).
+    uint32_t* seg_next;
+    uint32_t seg_range, n_paths;
+    // Totals and per-segment maxima per round, as pairs: [2k] = extend queue of round k+1 (k = 0..rounds),
+    // [2r+1] = shadow queue of round r.  One atomic add + two atomic max per workgroup and kernel.
     uint32_t* qcounts;
     uint32_t* qmax;
     uint32_t* cursors;     // [2 * max_bounces] work cursors of the persistent traversal launches
@@ -237,6 +243,7 @@ struct TravArgs {
     const uint32_t* max_ptr;
     uint32_t n_seg, seg_cap;
     uint32_t count_scale, fixed_count;
+    uint32_t internal;  // rays of the renderer's own extend queue: t in [0, f32::MAX], w fields carry path id / bounce
     int32_t root;    // descriptor of the root
     ptx_hit* hits;   // nearest-hit output (ANY == false)
     uint8_t* occ;    // occlusion output    (ANY == true)
@@ -326,8 +333,8 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                 ridx = lo + rank;
                 const float4 ra = reinterpret_cast<const float4*>(a.rays)[2 * (size_t)ridx];
                 const float4 rb = reinterpret_cast<const float4*>(a.rays)[2 * (size_t)ridx + 1];
-                ox = ra.x, oy = ra.y, oz = ra.z, t1 = ra.w;
-                dx = rb.x, dy = rb.y, dz = rb.z, t2 = t_end = rb.w;
+                ox = ra.x, oy = ra.y, oz = ra.z, t1 = a.internal ? 0.0f : ra.w;
+                dx = rb.x, dy = rb.y, dz = rb.z, t2 = t_end = a.internal ? 3.402823466e+38f : rb.w;
                 cur = a.root;
                 so = so0 + LVL;
                 PTX_SLOT(so0) = make_uint2(0u, f2u(t_end));
@@ -463,38 +470,44 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_generate(RenderState st) {
-    const uint32_t total = st.n_pixels * st.n_samples;
-    for (uint32_t pid = blockIdx.x * BLOCK + threadIdx.x; pid < total; pid += gridDim.x * BLOCK) {
-        const uint32_t pixel = pid % st.n_pixels, s = pid / st.n_pixels;
-        const uint32_t px = pixel % st.cam.width, py = pixel / st.cam.width;
-        const uint64_t key = ptx_path_key(st.seed, pixel, st.first_sample + s);
-        // sample_ray_for_pixel (pathtracer.rs:113-117) + Pinhole::ray (camera.rs:88-93)
-        const float cx = (float)px + ptx_u01(key, 0), cy = (float)py + ptx_u01(key, 1);
-        const float u = cx / (float)st.cam.width, v = cy / (float)st.cam.height;
-        ptx_ray r;
-        r.ox = st.cam.position[0];
-        r.oy = st.cam.position[1];
-        r.oz = st.cam.position[2];
-        r.tmin = 0.0f;
-        r.dx = st.cam.plane[0] + u * st.cam.dx[0] + v * st.cam.dy[0];
-        r.dy = st.cam.plane[1] + u * st.cam.dx[1] + v * st.cam.dy[1];
-        r.dz = st.cam.plane[2] + u * st.cam.dx[2] + v * st.cam.dy[2];
-        r.tmax = 3.402823466e+38f;
-        reinterpret_cast<float4*>(st.rays[0])[2 * (size_t)pid] = make_float4(r.ox, r.oy, r.oz, r.tmin);
-        reinterpret_cast<float4*>(st.rays[0])[2 * (size_t)pid + 1] = make_float4(r.dx, r.dy, r.dz, r.tmax);
-        st.pids[0][pid] = pid;
-        st.transport[pid] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-        st.radiance[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-    if (blockIdx.x == 0) {  // the first queue fills the segments in path order
-        for (uint32_t sg = threadIdx.x; sg < st.n_seg; sg += BLOCK) {
-            const unsigned long long first = (unsigned long long)sg * st.seg_cap;
-            st.seg_ext[0][sg] = first >= total ? 0u : (total - first < st.seg_cap ? (uint32_t)(total - first) : st.seg_cap);
-        }
+// sample_ray_for_pixel (pathtracer.rs:113-117) + Pinhole::ray (camera.rs:88-93): starts path `pid` in queue
+// slot `slot` and resets its state.
+__device__ inline void start_path(const RenderState& st, ptx_ray* __restrict__ rays, uint32_t slot, uint32_t pid) {
+    const uint32_t pixel = pid % st.n_pixels, s = pid / st.n_pixels;
+    const uint32_t px = pixel % st.cam.width, py = pixel / st.cam.width;
+    const uint64_t key = ptx_path_key(st.seed, pixel, st.first_sample + s);
+    const float cx = (float)px + ptx_u01(key, 0), cy = (float)py + ptx_u01(key, 1);
+    const float u = cx / (float)st.cam.width, v = cy / (float)st.cam.height;
+    const float dx = st.cam.plane[0] + u * st.cam.dx[0] + v * st.cam.dy[0];
+    const float dy = st.cam.plane[1] + u * st.cam.dx[1] + v * st.cam.dy[1];
+    const float dz = st.cam.plane[2] + u * st.cam.dx[2] + v * st.cam.dy[2];
+    reinterpret_cast<float4*>(rays)[2 * (size_t)slot] = make_float4(st.cam.position[0], st.cam.position[1], st.cam.position[2], u2f(pid));
+    reinterpret_cast<float4*>(rays)[2 * (size_t)slot + 1] = make_float4(dx, dy, dz, u2f(1u));
+    st.transport[pid] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    st.radiance[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// Tops segment `seg` of `rays` (holding `have` entries) up with the next unstarted paths of its range.
+// All threads of the workgroup call; returns the new entry count.
+__device__ inline uint32_t regenerate(const RenderState& st, ptx_ray* __restrict__ rays, uint32_t seg, uint32_t have, uint32_t started) {
+    const uint32_t range_lo = seg * st.seg_range;
+    const uint32_t range_n = range_lo >= st.n_paths ? 0u : (st.n_paths - range_lo < st.seg_range ? st.n_paths - range_lo : st.seg_range);
+    const uint32_t room = st.seg_cap - have, left = range_n - started;
+    const uint32_t k = room < left ? room : left;
+    for (uint32_t j = threadIdx.x; j < k; j += BLOCK) start_path(st, rays, seg * st.seg_cap + have + j, range_lo + started + j);
+    if (threadIdx.x == 0) st.seg_next[seg] = started + k;
+    return have + k;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_start(RenderState st) {
+    for (uint32_t seg = blockIdx.x; seg < st.n_seg; seg += gridDim.x) {
+        const uint32_t n = regenerate(st, st.rays[0], seg, 0u, 0u);
         if (threadIdx.x == 0) {
-            st.qcounts[0] = total;
-            st.qmax[0] = total < st.seg_cap ? total : st.seg_cap;
+            st.seg_ext[0][seg] = n;
+            if (n) {
+                atomicAdd(st.qcounts, n);
+                atomicMax(st.qmax, n);
+            }
         }
     }
 }
@@ -600,15 +613,12 @@ __device__ inline Bsdf material_sample(const DevMaterial& m, V3 wi, V3 n, float 
 
 // One bounce of trace_ray (pathtracer.rs:33-108) for every entry of the current extend queue.
 template <int NL /* compile-time light count, 0 = read it from the scene */>
-__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, uint32_t bounce /* 1-based */) {
+__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, uint32_t round /* 1-based */) {
     __shared__ uint32_t lds[4 * WAVES];
-    const uint32_t q = (bounce - 1u) & 1u;
+    const uint32_t q = (round - 1u) & 1u;
     const ptx_ray* __restrict__ rays_in = st.rays[q];
-    const uint32_t* __restrict__ pid_in = st.pids[q];
     ptx_ray* __restrict__ rays_out = st.rays[q ^ 1u];
-    uint32_t* __restrict__ pid_out = st.pids[q ^ 1u];
     const uint32_t n_lights = NL ? (uint32_t)NL : sc.n_lights;
-    const uint32_t base = ptx_dim_base(bounce, n_lights);
     constexpr int MAXL = NL ? NL : PTX_MAX_LIGHTS;
     uint32_t parity = 0;
 
@@ -616,19 +626,23 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, ui
     // of segment `seg` of the output queues
     for (uint32_t seg = blockIdx.x; seg < st.n_seg; seg += gridDim.x) {
     const uint32_t count = st.seg_ext[q][seg];
+    const uint32_t started = st.seg_next[seg];
     const uint32_t seg_base = seg * st.seg_cap;
     uint32_t n_next = 0, n_shadow = 0;
+    __syncthreads();  // everybody has read seg_next before thread 0 rewrites it below
     for (uint32_t start = 0; start < count; start += BLOCK) {
         const uint32_t i = seg_base + start + threadIdx.x;
         const bool active = start + threadIdx.x < count;
         bool emit_next = false, emit_shadow = false;
-        uint32_t pid = 0;
+        uint32_t pid = 0, bounce = 1;
         V3 next_o = v3(0, 0, 0), next_d = v3(0, 0, 0), point_above = v3(0, 0, 0), T_old = v3(0, 0, 0);
         V3 sh_dir[MAXL], sh_c[MAXL];
         if (active) {
-            pid = pid_in[i];
             const float4 ra = reinterpret_cast<const float4*>(rays_in)[2 * (size_t)i];
             const float4 rb = reinterpret_cast<const float4*>(rays_in)[2 * (size_t)i + 1];
+            pid = f2u(ra.w);
+            bounce = f2u(rb.w);  // 1-based: the bounce this ray has just traced
+            const uint32_t base = ptx_dim_base(bounce, n_lights);
             const uint4 hraw = reinterpret_cast<const uint4*>(st.hits)[i];
             const float4 Traw = st.transport[pid];
             const V3 T = v3(Traw.x, Traw.y, Traw.z);
@@ -704,10 +718,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, ui
         n_next += tot_n;
         n_shadow += tot_s;
         if (emit_next) {
-            reinterpret_cast<float4*>(rays_out)[2 * (size_t)slot_n] = make_float4(next_o.x, next_o.y, next_o.z, 0.0f);
-            reinterpret_cast<float4*>(rays_out)[2 * (size_t)slot_n + 1] =
-                make_float4(next_d.x, next_d.y, next_d.z, 3.402823466e+38f);
-            pid_out[slot_n] = pid;
+            reinterpret_cast<float4*>(rays_out)[2 * (size_t)slot_n] = make_float4(next_o.x, next_o.y, next_o.z, u2f(pid));
+            reinterpret_cast<float4*>(rays_out)[2 * (size_t)slot_n + 1] = make_float4(next_d.x, next_d.y, next_d.z, u2f(bounce + 1u));
         }
         if (emit_shadow) {
             // one light: the record is the product k_resolve would form (0 + c == c, so T * (0 + c) == T * c
@@ -722,14 +734,15 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, ui
             }
         }
     }
+    n_next = regenerate(st, rays_out, seg, n_next, started);  // fresh camera rays into the freed slots
     if (threadIdx.x == 0) {
         st.seg_ext[q ^ 1u][seg] = n_next;
         st.seg_sh[seg] = n_shadow;
         if (n_next | n_shadow) {
-            atomicAdd(reinterpret_cast<unsigned long long*>(st.qcounts + 2u * bounce),
+            atomicAdd(reinterpret_cast<unsigned long long*>(st.qcounts + 2u * round),
                       (unsigned long long)n_next | ((unsigned long long)n_shadow << 32));
-            atomicMax(st.qmax + 2u * bounce, n_next);
-            atomicMax(st.qmax + 2u * bounce + 1u, n_shadow);
+            atomicMax(st.qmax + 2u * round, n_next);
+            atomicMax(st.qmax + 2u * round + 1u, n_shadow);
         }
     }
     }
@@ -789,10 +802,10 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(RenderState st, float* __r
     }
 }
 
-__global__ void k_tally(RenderState st, uint32_t max_bounces, uint32_t n_lights) {
+__global__ void k_tally(RenderState st, uint32_t rounds, uint32_t n_lights) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         unsigned long long e = 0, s = 0;
-        for (uint32_t b = 0; b < max_bounces; ++b) {
+        for (uint32_t b = 0; b < rounds; ++b) {
             e += st.qcounts[2u * b];
             s += (unsigned long long)st.qcounts[2u * b + 3u] * n_lights;
         }
@@ -862,8 +875,9 @@ struct ptx_scene {
 
     // render state (allocated on first render, grown on demand)
     uint32_t batch_samples = 0;  // 0 = choose from the image size
-    size_t cap_paths = 0;
-    uint32_t cap_lights = 0, cap_bounces = 0;
+    uint64_t slot_budget = 0;    // queue slots over all pipelines, 0 = default (PTX_SLOTS_MI environment variable: Mi slots)
+    size_t cap_slots = 0, cap_paths = 0;
+    uint32_t cap_rounds = 0, last_rounds = 0;
     // One pipeline = the queues and state of one sample batch in flight on its own stream.  Batches are
     // independent until their accumulate step, so several run concurrently: the long-ray tails of the
     // late bounces of one batch (a few waves busy, the rest of the chip idle) overlap with the wide early
@@ -878,7 +892,6 @@ struct ptx_scene {
         DevBuf<uint2> spill2;
         hipEvent_t ev_accum = nullptr, ev_join = nullptr;
         DevBuf<ptx_ray> rays[2];
-        DevBuf<uint32_t> pids[2];
         DevBuf<ptx_hit> hits;
         DevBuf<float4> transport, radiance, sh_T, sh_contrib;
         DevBuf<ptx_ray> sh_rays;
@@ -976,14 +989,18 @@ void resolve_stamps(ptx_scene* sc) {
     sc->stamps.clear();
 }
 
-int ensure_render_state(ptx_scene* sc, size_t paths) {
+// slots = queue entries per pipeline (n_seg x seg_cap), paths = path ids per batch (radiance / transport),
+// rounds = extend/shade/shadow rounds per batch (bookkeeping words)
+int ensure_render_state(ptx_scene* sc, size_t slots, size_t paths, uint32_t rounds) {
     const uint32_t L = sc->dev.n_lights ? sc->dev.n_lights : 1u;
-    const uint32_t B = sc->dev.max_bounces;
-    if (sc->pipes.size() == sc->n_pipes && paths <= sc->cap_paths && L <= sc->cap_lights && B <= sc->cap_bounces)
+    if (sc->pipes.size() == sc->n_pipes && slots <= sc->cap_slots && paths <= sc->cap_paths && rounds <= sc->cap_rounds)
         return PTX_OK;
     HIP_TRY(hipDeviceSynchronize());
     if (!sc->ev_fork) HIP_TRY(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
-    if (paths < sc->cap_paths) paths = sc->cap_paths;  // every pipeline, old or new, holds the high-water mark
+    // every pipeline, old or new, holds the high-water marks
+    if (slots < sc->cap_slots) slots = sc->cap_slots;
+    if (paths < sc->cap_paths) paths = sc->cap_paths;
+    if (rounds < sc->cap_rounds) rounds = sc->cap_rounds;
     sc->pipes.resize(sc->n_pipes);
     sc->last_pipe = 0;
     for (auto& up : sc->pipes) {
@@ -999,27 +1016,24 @@ int ensure_render_state(ptx_scene* sc, size_t paths) {
             HIP_TRY(up->spill2.ensure((size_t)(PTX_MAX_DEPTH - LDS_DEPTH) * sc->tgrid * TBLOCK));
         }
         ptx_scene::Pipe& p = *up;
-        for (int q = 0; q < 2; ++q) {
-            HIP_TRY(p.rays[q].ensure(paths));
-            HIP_TRY(p.pids[q].ensure(paths));
-        }
-        HIP_TRY(p.hits.ensure(paths));
+        for (int q = 0; q < 2; ++q) HIP_TRY(p.rays[q].ensure(slots));
+        HIP_TRY(p.hits.ensure(slots));
         HIP_TRY(p.transport.ensure(paths));
         HIP_TRY(p.radiance.ensure(paths));
-        HIP_TRY(p.sh_T.ensure(paths));
-        HIP_TRY(p.sh_rays.ensure(paths * L));
-        HIP_TRY(p.sh_contrib.ensure(paths * L));
-        HIP_TRY(p.sh_occ.ensure(paths * L));
-        HIP_TRY(p.counts.ensure(6 * (size_t)B + 4));
-        HIP_TRY(p.segs.ensure(3 * (size_t)sc->shade_grid));
+        HIP_TRY(p.sh_T.ensure(slots));
+        HIP_TRY(p.sh_rays.ensure(slots * L));
+        if (L > 1) HIP_TRY(p.sh_contrib.ensure(slots * L));
+        HIP_TRY(p.sh_occ.ensure(slots * L));
+        HIP_TRY(p.counts.ensure(6 * (size_t)rounds + 4));
+        HIP_TRY(p.segs.ensure(4 * (size_t)sc->shade_grid));
     }
     if (!sc->totals.p) {
         HIP_TRY(sc->totals.ensure(32));
         HIP_TRY(hipMemset(sc->totals.p, 0, 32 * sizeof(unsigned long long)));
     }
-    sc->cap_paths = paths > sc->cap_paths ? paths : sc->cap_paths;
-    sc->cap_lights = L > sc->cap_lights ? L : sc->cap_lights;
-    sc->cap_bounces = B > sc->cap_bounces ? B : sc->cap_bounces;
+    sc->cap_slots = slots;
+    sc->cap_paths = paths;
+    sc->cap_rounds = rounds;
     return PTX_OK;
 }
 
@@ -1106,6 +1120,7 @@ struct SegRange {  // a segmented queue as the traversal kernel sees it (see Ren
     const uint32_t* counts = nullptr;
     const uint32_t* max_ptr = nullptr;
     uint32_t n_seg = 1, cap = 0, scale = 1;
+    bool internal = false;
 };
 
 template <bool ANY>
@@ -1124,6 +1139,7 @@ int launch_traverse(ptx_scene* sc, const ptx_ray* d_rays, const SegRange& sr, ui
     a.n_seg = sr.n_seg;
     a.seg_cap = sr.cap;
     a.count_scale = sr.scale;
+    a.internal = sr.internal ? 1u : 0u;
     a.fixed_count = n;
     a.hits = d_hits;
     a.occ = d_occ;
@@ -1195,6 +1211,10 @@ int ptx_scene_create(const ptx_scene_desc* d, uint32_t flags, ptx_scene** out) {
     sc->tgrid = prop.multiProcessorCount * PTX_BLOCKS_PER_CU;  // sized so that the LDS of a CU is filled
     sc->flags = flags;
     if (const char* e = getenv("PTX_OVERLAP")) sc->overlap_shadow = atoi(e) != 0;
+    if (const char* e = getenv("PTX_SLOTS_MI")) {
+        const long v = atol(e);
+        if (v >= 1 && v <= 511) sc->slot_budget = (uint64_t)v << 20;
+    }
     if (const char* e = getenv("PTX_PIPES")) {
         int k = atoi(e);
         if (k >= 1 && k <= 8) sc->n_pipes = (uint32_t)k;
@@ -1326,6 +1346,13 @@ int ptx_set_batch_samples(ptx_scene* sc, uint32_t samples_per_batch) {
     return PTX_OK;
 }
 
+int ptx_set_queue_slots(ptx_scene* sc, uint64_t slots) {
+    if (!sc) return fail(PTX_E_ARG, "ptx_set_queue_slots: null scene");
+    if (slots >= (1ull << 29)) return fail(PTX_E_LIMIT, "ptx_set_queue_slots: at most 2^29 - 1 slots");
+    sc->slot_budget = slots;
+    return PTX_OK;
+}
+
 int ptx_set_pipelines(ptx_scene* sc, uint32_t n) {
     int rc = check_scene(sc, "ptx_set_pipelines");
     if (rc) return rc;
@@ -1345,20 +1372,27 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
     if (n_pixels64 > (1ull << 27)) return fail(PTX_E_LIMIT, "ptx_render: image larger than 2^27 pixels");
     if ((uint64_t)first_sample + sample_count > 0xFFFFFFFFull) return fail(PTX_E_LIMIT, "ptx_render: sample index overflow");
     const uint32_t n_pixels = (uint32_t)n_pixels64;
-    // Batch size: large batches amortise the long-ray tail of every launch (measured at 1080^2: 5 -> 64 ->
-    // 128 -> 192 samples per batch raises the traversal kernels from 2.5 to ~7 / 11.2 / 11.6 Grays/s).  ~230 B
-    // of queue state per path: the default budget of 320 Mi paths in flight is ~77 GB of the 288 GB of HBM.
-    // With more than one pipeline (ptx_set_pipelines) the batches of a call are spread evenly over them.
+    // Batches.  The last rays of a launch finish ~0.3 ms after its cursor drains, and the late bounces of a
+    // batch are small launches that cannot fill the chip (measured at 1080^2: 64 / 128 / 256 / 448 samples per
+    // batch = 1.0 / 1.26 / 1.35 / 1.45 G samples/s), so a batch should be as long as possible.  Two budgets
+    // bound it: queue SLOTS (~200 B each; default 320 Mi = ~67 GB of the 288 GB) and path ids (32 B of
+    // radiance + transport each, < 2^29).  A batch with more paths than slots runs with path regeneration:
+    // every queue segment starts the next paths of its range as earlier ones end (see RenderState), so all
+    // launches but the last few stay slot-wide.
     const uint32_t n_pipes = sc->n_pipes;
-    uint32_t S = sc->batch_samples;
+    const uint32_t B = sc->dev.max_bounces, L = sc->dev.n_lights;
+    const uint64_t slot_budget = (sc->slot_budget ? sc->slot_budget : (320ull << 20)) / n_pipes;
+    const uint64_t max_batch_paths = (1ull << 29) - (1ull << 20);
+    uint32_t S = sc->batch_samples;  // samples per batch
     if (S == 0) {
-        const uint64_t budget = (320ull << 20) / ((uint64_t)n_pipes * n_pixels);
-        S = (uint32_t)(budget < 1 ? 1 : (budget > 256 ? 256 : budget));
+        // up to 8 slot-loads of paths per batch (bounds the number of rounds), spread evenly over the pipelines
+        const uint64_t by_rounds = 8 * slot_budget / n_pixels, by_ids = max_batch_paths / n_pixels;
+        uint64_t most = by_rounds < by_ids ? by_rounds : by_ids;
+        if (most < 1) most = 1;
         const uint32_t per_pipe = (sample_count + n_pipes - 1) / n_pipes;
-        if (per_pipe > 0 && per_pipe < S) S = per_pipe;
+        S = (uint32_t)(most < per_pipe ? most : (per_pipe ? per_pipe : 1));
     }
-    // queue slots (with segment padding) stay < 2^29, so that slot * n_lights + light (<= 8 lights) fits 32 bits
-    while ((uint64_t)S * n_pixels > (1ull << 29) - (1ull << 20)) S = (S + 1) / 2;
+    while ((uint64_t)S * n_pixels > max_batch_paths && S > 1) S = (S + 1) / 2;
     if (S < 1) S = 1;
     if (sample_count > 0) {  // equal-sized batches, their number a multiple of the pipeline count when possible
         uint32_t n_batches = (sample_count + S - 1) / S;
@@ -1366,16 +1400,23 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         if (n_batches > sample_count) n_batches = sample_count;
         S = (sample_count + n_batches - 1) / n_batches;
     }
-    // queue segments (see RenderState): one per k_shade workgroup, sized for a full batch
+    // queue segments (see RenderState): one per k_shade workgroup; seg_range paths each, seg_cap of them live
     const uint64_t batch_paths = (uint64_t)S * n_pixels;
     uint32_t n_seg = (uint32_t)sc->shade_grid;
     if ((batch_paths + 255) / 256 < n_seg) n_seg = (uint32_t)((batch_paths + 255) / 256);
     if (n_seg < 1) n_seg = 1;
-    const uint32_t seg_cap = (uint32_t)(((batch_paths + n_seg - 1) / n_seg + 63) / 64 * 64);
-    int rc = ensure_render_state(sc, (size_t)n_seg * seg_cap);
+    const uint32_t seg_range = (uint32_t)((batch_paths + n_seg - 1) / n_seg);
+    uint32_t seg_cap = (uint32_t)((seg_range + 63) / 64 * 64);
+    {
+        const uint64_t by_budget = slot_budget / n_seg / 64 * 64;
+        if (by_budget >= 64 && by_budget < seg_cap) seg_cap = (uint32_t)by_budget;
+    }
+    // a slot turns over after at most B rounds: B x ceil(range / cap) rounds start and finish every path
+    const uint32_t rounds = B * ((seg_range + seg_cap - 1) / seg_cap);
+    int rc = ensure_render_state(sc, (size_t)n_seg * seg_cap, (size_t)batch_paths, rounds);
     if (rc) return rc;
+    sc->last_rounds = rounds;
 
-    const uint32_t B = sc->dev.max_bounces, L = sc->dev.n_lights;
     const int grid = sc->grid;
     auto t0 = std::chrono::steady_clock::now();
     // fork: the pipelines start after everything already queued on the caller's stream
@@ -1391,8 +1432,6 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         RenderState st{};
         st.rays[0] = p.rays[0].p;
         st.rays[1] = p.rays[1].p;
-        st.pids[0] = p.pids[0].p;
-        st.pids[1] = p.pids[1].p;
         st.hits = p.hits.p;
         st.transport = p.transport.p;
         st.radiance = p.radiance.p;
@@ -1401,28 +1440,33 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         st.sh_contrib = p.sh_contrib.p;
         st.sh_occ = p.sh_occ.p;
         st.qcounts = p.counts.p;
-        st.qmax = p.counts.p + (2 * B + 2);
-        st.cursors = p.counts.p + (4 * B + 4);
+        st.qmax = p.counts.p + (2 * rounds + 2);
+        st.cursors = p.counts.p + (4 * rounds + 4);
         st.seg_ext[0] = p.segs.p;
         st.seg_ext[1] = p.segs.p + n_seg;
         st.seg_sh = p.segs.p + 2 * (size_t)n_seg;
+        st.seg_next = p.segs.p + 3 * (size_t)n_seg;
         st.n_seg = n_seg;
         st.seg_cap = seg_cap;
+        st.seg_range = seg_range;
         st.totals = sc->totals.p;
         st.cam = *cam;
         st.seed = seed;
         st.n_pixels = n_pixels;
         st.n_samples = ns;
+        st.n_paths = ns * n_pixels;
         st.first_sample = first_sample + done;
-        HIP_TRY(hipMemsetAsync(p.counts.p, 0, (6 * (size_t)B + 4) * sizeof(uint32_t), stream));
-        {
+        HIP_TRY(hipMemsetAsync(p.counts.p, 0, (6 * (size_t)rounds + 4) * sizeof(uint32_t), stream));
+        if (rounds == 0) {  // max_bounces == 0: nothing is traced (the reference's loop body never runs)
+            HIP_TRY(hipMemsetAsync(p.radiance.p, 0, (size_t)st.n_paths * sizeof(float4), stream));
+        } else {
             Timed tm(sc, stream, KC_GENERATE);
-            k_generate<<<grid, BLOCK, 0, stream>>>(st);
+            k_start<<<(int)n_seg, BLOCK, 0, stream>>>(st);
         }
         const bool overlap = sc->overlap_shadow && L > 0;
         hipStream_t sstream = overlap ? p.stream2 : stream;  // stream of the shadow launches
         uint2* sspill = overlap ? p.spill2.p : p.spill.p;
-        for (uint32_t b = 1; b <= B; ++b) {
+        for (uint32_t b = 1; b <= rounds; ++b) {
             {
                 Timed tm(sc, stream, KC_EXTEND);
                 ++sc->extend_launches;
@@ -1431,6 +1475,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
                 sr.max_ptr = st.qmax + 2 * (b - 1);
                 sr.n_seg = n_seg;
                 sr.cap = seg_cap;
+                sr.internal = true;
                 rc = launch_traverse<false>(sc, st.rays[(b - 1) & 1], sr, 0, st.hits, nullptr, st.cursors + 2 * (b - 1),
                                             p.spill.p, sc->totals.p + 2, stream);
                 if (rc) return rc;
@@ -1476,7 +1521,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         {
             Timed tm(sc, stream, KC_OTHER);
             k_accumulate<<<grid, BLOCK, 0, stream>>>(st, d_accum);
-            k_tally<<<1, 64, 0, stream>>>(st, B, L);
+            k_tally<<<1, 64, 0, stream>>>(st, rounds, L);
         }
         HIP_TRY(hipEventRecord(p.ev_accum, stream));
         prev_accum = p.ev_accum;
@@ -1525,7 +1570,7 @@ int ptx_last_batch_counts(ptx_scene* sc, uint32_t* ext, uint32_t* sh, uint32_t n
     int rc = check_scene(sc, "ptx_last_batch_counts");
     if (rc) return rc;
     if (!ext || !sh) return fail(PTX_E_ARG, "ptx_last_batch_counts: null argument");
-    const uint32_t B = sc->cap_bounces;
+    const uint32_t B = sc->last_rounds;
     if (sc->pipes.empty() || B == 0) return fail(PTX_E_ARG, "ptx_last_batch_counts: nothing rendered yet");
     HIP_TRY(hipDeviceSynchronize());
     std::vector<uint32_t> host(2 * (size_t)B + 4);

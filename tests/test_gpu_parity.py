@@ -139,6 +139,13 @@ def test_render_bit_exact_vs_oracle_counter_mode(name, w, h, spp, bounces):
     dev.set_batch_samples(0)
     again = dev.render(scene.pinhole(w, h), spp, seed=77, first_sample=5)
     assert again.tobytes() == got.tobytes()
+    # nor must path regeneration: with a quarter of the queue slots the batch needs, finished paths are
+    # replaced by the next camera rays round after round (64 slots per segment, the minimum)
+    dev.set_queue_slots(64 * ((w * h * spp + 255) // 256))
+    again = dev.render(scene.pinhole(w, h), spp, seed=77, first_sample=5)
+    assert again.tobytes() == got.tobytes()
+    ext, _ = dev.last_batch_counts()
+    assert len(ext) > bounces  # it really took more rounds than bounces
     dev.close()
 
 
