@@ -61,7 +61,7 @@ struct DevScene {
 struct RenderState {
     ptx_ray* rays[2];
     ptx_hit* hits;
-    float4* transport;
+    float4* transq[2];  // accumulated transport of the entries of extend queue A / B (travels with the ray)
     float4* radiance;
     ptx_ray* sh_rays;    // [i * n_lights + l] shadow ray: origin point_above, direction target - origin, t in [0,1]
     float4* sh_T;        // [i] {transport before this bounce's update, bits(pid)}
@@ -472,7 +472,8 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
 
 // sample_ray_for_pixel (pathtracer.rs:113-117) + Pinhole::ray (camera.rs:88-93): starts path `pid` in queue
 // slot `slot` and resets its state.
-__device__ inline void start_path(const RenderState& st, ptx_ray* __restrict__ rays, uint32_t slot, uint32_t pid) {
+__device__ inline void start_path(const RenderState& st, ptx_ray* __restrict__ rays, float4* __restrict__ trans, uint32_t slot,
+                                  uint32_t pid) {
     const uint32_t pixel = pid % st.n_pixels, s = pid / st.n_pixels;
     const uint32_t px = pixel % st.cam.width, py = pixel / st.cam.width;
     const uint64_t key = ptx_path_key(st.seed, pixel, st.first_sample + s);
@@ -483,25 +484,26 @@ __device__ inline void start_path(const RenderState& st, ptx_ray* __restrict__ r
     const float dz = st.cam.plane[2] + u * st.cam.dx[2] + v * st.cam.dy[2];
     reinterpret_cast<float4*>(rays)[2 * (size_t)slot] = make_float4(st.cam.position[0], st.cam.position[1], st.cam.position[2], u2f(pid));
     reinterpret_cast<float4*>(rays)[2 * (size_t)slot + 1] = make_float4(dx, dy, dz, u2f(1u));
-    st.transport[pid] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    trans[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
     st.radiance[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 // Tops segment `seg` of `rays` (holding `have` entries) up with the next unstarted paths of its range.
 // All threads of the workgroup call; returns the new entry count.
-__device__ inline uint32_t regenerate(const RenderState& st, ptx_ray* __restrict__ rays, uint32_t seg, uint32_t have, uint32_t started) {
+__device__ inline uint32_t regenerate(const RenderState& st, ptx_ray* __restrict__ rays, float4* __restrict__ trans, uint32_t seg,
+                                      uint32_t have, uint32_t started) {
     const uint32_t range_lo = seg * st.seg_range;
     const uint32_t range_n = range_lo >= st.n_paths ? 0u : (st.n_paths - range_lo < st.seg_range ? st.n_paths - range_lo : st.seg_range);
     const uint32_t room = st.seg_cap - have, left = range_n - started;
     const uint32_t k = room < left ? room : left;
-    for (uint32_t j = threadIdx.x; j < k; j += BLOCK) start_path(st, rays, seg * st.seg_cap + have + j, range_lo + started + j);
+    for (uint32_t j = threadIdx.x; j < k; j += BLOCK) start_path(st, rays, trans, seg * st.seg_cap + have + j, range_lo + started + j);
     if (threadIdx.x == 0) st.seg_next[seg] = started + k;
     return have + k;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_start(RenderState st) {
     for (uint32_t seg = blockIdx.x; seg < st.n_seg; seg += gridDim.x) {
-        const uint32_t n = regenerate(st, st.rays[0], seg, 0u, 0u);
+        const uint32_t n = regenerate(st, st.rays[0], st.transq[0], seg, 0u, 0u);
         if (threadIdx.x == 0) {
             st.seg_ext[0][seg] = n;
             if (n) {
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, ui
         const bool active = start + threadIdx.x < count;
         bool emit_next = false, emit_shadow = false;
         uint32_t pid = 0, bounce = 1;
-        V3 next_o = v3(0, 0, 0), next_d = v3(0, 0, 0), point_above = v3(0, 0, 0), T_old = v3(0, 0, 0);
+        V3 next_o = v3(0, 0, 0), next_d = v3(0, 0, 0), point_above = v3(0, 0, 0), T_old = v3(0, 0, 0), T_next = v3(0, 0, 0);
         V3 sh_dir[MAXL], sh_c[MAXL];
         if (active) {
             const float4 ra = reinterpret_cast<const float4*>(rays_in)[2 * (size_t)i];
@@ -644,7 +646,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, ui
             bounce = f2u(rb.w);  // 1-based: the bounce this ray has just traced
             const uint32_t base = ptx_dim_base(bounce, n_lights);
             const uint4 hraw = reinterpret_cast<const uint4*>(st.hits)[i];
-            const float4 Traw = st.transport[pid];
+            const float4 Traw = st.transq[q][i];
             const V3 T = v3(Traw.x, Traw.y, Traw.z);
             if (hraw.x == PTX_MISS) {
                 // return accumulated_radiance + accumulated_transport * environment (pathtracer.rs:44-46)
@@ -701,9 +703,9 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, ui
                     V3 Tn;
                     if (smp.is_delta) Tn = T * smp.bsdf;
                     else Tn = T * (smp.bsdf * (fabsf(cosine) / smp.pdf));
-                    st.transport[pid] = make_float4(Tn.x, Tn.y, Tn.z, 0.0f);
                     if (!(dot(Tn, Tn) <= 1.0e-4f) && bounce < sc.max_bounces) {
                         emit_next = true;
+                        T_next = Tn;
                         next_o = cosine >= 0.0f ? point_above : point_below;
                         next_d = smp.wo;
                     }
@@ -720,6 +722,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, ui
         if (emit_next) {
             reinterpret_cast<float4*>(rays_out)[2 * (size_t)slot_n] = make_float4(next_o.x, next_o.y, next_o.z, u2f(pid));
             reinterpret_cast<float4*>(rays_out)[2 * (size_t)slot_n + 1] = make_float4(next_d.x, next_d.y, next_d.z, u2f(bounce + 1u));
+            st.transq[q ^ 1u][slot_n] = make_float4(T_next.x, T_next.y, T_next.z, 0.0f);
         }
         if (emit_shadow) {
             // one light: the record is the product k_resolve would form (0 + c == c, so T * (0 + c) == T * c
@@ -734,7 +737,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, ui
             }
         }
     }
-    n_next = regenerate(st, rays_out, seg, n_next, started);  // fresh camera rays into the freed slots
+    n_next = regenerate(st, rays_out, st.transq[q ^ 1u], seg, n_next, started);  // fresh camera rays into the freed slots
     if (threadIdx.x == 0) {
         st.seg_ext[q ^ 1u][seg] = n_next;
         st.seg_sh[seg] = n_shadow;
@@ -893,7 +896,7 @@ struct ptx_scene {
         hipEvent_t ev_accum = nullptr, ev_join = nullptr;
         DevBuf<ptx_ray> rays[2];
         DevBuf<ptx_hit> hits;
-        DevBuf<float4> transport, radiance, sh_T, sh_contrib;
+        DevBuf<float4> transq[2], radiance, sh_T, sh_contrib;
         DevBuf<ptx_ray> sh_rays;
         DevBuf<uint8_t> sh_occ;
         DevBuf<uint2> spill;
@@ -989,7 +992,7 @@ void resolve_stamps(ptx_scene* sc) {
     sc->stamps.clear();
 }
 
-// slots = queue entries per pipeline (n_seg x seg_cap), paths = path ids per batch (radiance / transport),
+// slots = queue entries per pipeline (n_seg x seg_cap), paths = path ids per batch (radiance),
 // rounds = extend/shade/shadow rounds per batch (bookkeeping words)
 int ensure_render_state(ptx_scene* sc, size_t slots, size_t paths, uint32_t rounds) {
     const uint32_t L = sc->dev.n_lights ? sc->dev.n_lights : 1u;
@@ -1016,9 +1019,11 @@ int ensure_render_state(ptx_scene* sc, size_t slots, size_t paths, uint32_t roun
             HIP_TRY(up->spill2.ensure((size_t)(PTX_MAX_DEPTH - LDS_DEPTH) * sc->tgrid * TBLOCK));
         }
         ptx_scene::Pipe& p = *up;
-        for (int q = 0; q < 2; ++q) HIP_TRY(p.rays[q].ensure(slots));
+        for (int q = 0; q < 2; ++q) {
+            HIP_TRY(p.rays[q].ensure(slots));
+            HIP_TRY(p.transq[q].ensure(slots));
+        }
         HIP_TRY(p.hits.ensure(slots));
-        HIP_TRY(p.transport.ensure(paths));
         HIP_TRY(p.radiance.ensure(paths));
         HIP_TRY(p.sh_T.ensure(slots));
         HIP_TRY(p.sh_rays.ensure(slots * L));
@@ -1375,8 +1380,8 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
     // Batches.  The last rays of a launch finish ~0.3 ms after its cursor drains, and the late bounces of a
     // batch are small launches that cannot fill the chip (measured at 1080^2: 64 / 128 / 256 / 448 samples per
     // batch = 1.0 / 1.26 / 1.35 / 1.45 G samples/s), so a batch should be as long as possible.  Two budgets
-    // bound it: queue SLOTS (~200 B each; default 320 Mi = ~67 GB of the 288 GB) and path ids (32 B of
-    // radiance + transport each, < 2^29).  A batch with more paths than slots runs with path regeneration:
+    // bound it: queue SLOTS (~215 B each; default 320 Mi = ~67 GB of the 288 GB) and path ids (16 B of
+    // radiance each, < 2^29).  A batch with more paths than slots runs with path regeneration:
     // every queue segment starts the next paths of its range as earlier ones end (see RenderState), so all
     // launches but the last few stay slot-wide.
     const uint32_t n_pipes = sc->n_pipes;
@@ -1433,7 +1438,8 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         st.rays[0] = p.rays[0].p;
         st.rays[1] = p.rays[1].p;
         st.hits = p.hits.p;
-        st.transport = p.transport.p;
+        st.transq[0] = p.transq[0].p;
+        st.transq[1] = p.transq[1].p;
         st.radiance = p.radiance.p;
         st.sh_rays = p.sh_rays.p;
         st.sh_T = p.sh_T.p;
