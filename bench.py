@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--save", default="", help="write the tonemapped image (rank 0) to this PNG")
+    ap.add_argument("--force-dist", action="store_true", help="run the torch.distributed path even with one rank (rehearsal)")
     args = ap.parse_args()
 
     import numpy as np
@@ -61,8 +62,12 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     W, H = (int(x) for x in args.size.lower().split("x"))
@@ -85,13 +90,13 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
     for i in range(args.warmup):
         step(i)
-    if world > 1:  # warm the communicator too
+    if use_dist:  # warm the communicator too
         dist.reduce(torch.zeros(16, device="cuda"), dst=0)
     fence()
     accum.zero_()
@@ -100,18 +105,18 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
-    if world > 1:
+    if use_dist:
         dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     st = dev.stats()
     counts = torch.tensor([st["extend_rays"], st["shadow_rays"], st["samples"]], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     extend_rays, shadow_rays, samples = (float(x) for x in counts.tolist())
 
@@ -200,7 +205,7 @@ def main():
             img = pt.to_rgb8(accum.cpu().numpy().reshape(H, W, 3), int(samples / (W * H)))
             pt.write_png(args.save, img)
     dev.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
