@@ -1,0 +1,152 @@
+"""GPU edge cases (-m gpu): light counts that take the generic shade kernel (0, 3, 8 lights), bounce limits,
+a scene without geometry, ragged and empty ray batches, rays that can never hit, non-finite rays (must
+terminate), and the argument errors of the C ABI."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+import pathtracer_amd as pt
+import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCENES = os.path.join(ROOT, "scenes")
+f32 = np.float32
+
+
+def cornell_with_lights(tmp_path, n_lights):
+    """cornell.obj with its MTL rewritten to carry `n_lights` lights (custom MTL syntax, wavefront/src/mtl.rs)."""
+    src_obj, src_mtl = os.path.join(SCENES, "cornell.obj"), os.path.join(SCENES, "cornell.mtl")
+    obj = tmp_path / "cornell.obj"
+    shutil.copy(src_obj, obj)
+    lines, skipping = [], False
+    for line in open(src_mtl):
+        if line.startswith("newlight"):
+            skipping = True
+            continue
+        if skipping and line.strip().startswith("light"):
+            continue
+        skipping = False
+        lines.append(line)
+    rng = np.random.default_rng(n_lights)
+    lights = []
+    for i in range(n_lights):
+        p, c = rng.uniform(-0.7, 0.7, 3), rng.uniform(0.3, 1.0, 3)
+        lights.append("newlight L%d\n\tlightposition %.3f %.3f %.3f\n\tlightcolor %.3f %.3f %.3f\n\tlightradius %.2f\n\tlightintensity %.2f\n\n"
+                      % (i, p[0], abs(p[1]), p[2], c[0], c[1], c[2], 0.05 + 0.05 * i, 1.0 + 0.5 * i))
+    (tmp_path / "cornell.mtl").write_text("".join(lights) + "".join(lines))
+    return str(obj)
+
+
+@pytest.mark.parametrize("n_lights", [0, 3, 8])
+def test_light_counts_of_the_generic_shade_kernel(tmp_path, n_lights):
+    path = cornell_with_lights(tmp_path, n_lights)
+    ref = orc.Scene(path, max_bounces=5)
+    assert ref.counts["lights"] == n_lights
+    want, _, st = ref.render(40, 32, threads=1, iterations_per_thread=2, mode=1, seed=4, stats=True)
+    scene = pt.LoadedScene(path, max_bounces=5)
+    dev = scene.upload()
+    got = dev.render(scene.pinhole(40, 32), 2, seed=4)
+    assert got.tobytes() == want.tobytes()
+    s = dev.stats()
+    assert s["extend_rays"] == st["extend_rays"] and s["shadow_rays"] == st["shadow_rays"]
+    assert (s["shadow_rays"] == 0) == (n_lights == 0)
+    dev.close()
+
+
+@pytest.mark.parametrize("bounces", [0, 1, 2, 40])
+def test_bounce_limits(bounces):
+    path = os.path.join(SCENES, "cornell_textured.obj")
+    ref = orc.Scene(path, max_bounces=bounces)
+    want, _ = ref.render(32, 32, threads=1, iterations_per_thread=2, mode=1, seed=8)
+    scene = pt.LoadedScene(path, max_bounces=bounces)
+    dev = scene.upload()
+    got = dev.render(scene.pinhole(32, 32), 2, seed=8)
+    assert got.tobytes() == want.tobytes()
+    if bounces == 0:
+        assert not got.any()  # the reference's loop body never runs: black
+    dev.close()
+
+
+def one_leaf(count):
+    n = np.zeros(1, pt.NODE_DTYPE)
+    n["w0"], n["w1"] = 0, (count << 2) | 3
+    return n
+
+
+def test_scene_without_geometry_and_ragged_batches():
+    import torch
+
+    empty = pt.DeviceScene.from_arrays(np.zeros((0, 9), f32), one_leaf(0), np.zeros(0, np.uint32))
+    for n in (0, 1, 63, 64, 65, 1000):
+        rays = pt.make_rays(np.zeros((n, 3), f32), np.tile(f32([0, 0, -1]), (n, 1)))
+        hits = empty.intersect(rays)
+        assert len(hits) == n and (hits["index"] == pt.MISS).all() and not hits["t"].any()
+    empty.close()
+    # one triangle, the tree a single one-triangle leaf: hit / miss / out of range / parallel / behind
+    tri = f32([[-1, -1, -2, 1, -1, -2, 0, 1, -2]])
+    dev = pt.DeviceScene.from_arrays(tri, one_leaf(1), np.array([0], np.uint32))
+    o = f32([[0, 0, 0], [5, 5, 0], [0, 0, 0], [0, 0, 0], [0, 0, -3]])
+    d = f32([[0, 0, -1], [0, 0, -1], [0, 0, -1], [1, 0, 0], [0, 0, -1]])
+    rays = pt.make_rays(o, d)
+    rays["tmax"][2] = 1.5  # the triangle is at t = 2
+    hits = dev.intersect(rays)
+    assert hits["index"].tolist() == [0, pt.MISS, pt.MISS, pt.MISS, pt.MISS] and hits["t"][0] == 2.0
+    # device-buffer entry point with n == 0 is a no-op
+    buf = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    dev.intersect_device(buf.data_ptr(), 0, buf.data_ptr())
+    dev.occluded_device(buf.data_ptr(), 0, buf.data_ptr())
+    dev.close()
+
+
+def test_non_finite_rays_terminate_and_match_the_host_traversal():
+    path = os.path.join(SCENES, "cornell_teapot.obj")
+    scene = pt.LoadedScene(path)
+    kd = scene.kdtree()
+    rng = np.random.default_rng(3)
+    n = 4096
+    o = rng.uniform(-1, 1, (n, 3)).astype(f32)
+    d = rng.normal(size=(n, 3)).astype(f32)
+    bad = rng.integers(0, 6, n)
+    d[bad == 0, 0] = np.nan
+    d[bad == 1] = 0.0
+    d[bad == 2, 1] = np.inf
+    o[bad == 3, 2] = np.nan
+    o[bad == 4, 0] = -np.inf
+    rays = pt.make_rays(o, d)
+    rays["tmax"][bad == 5] = np.inf
+    dev = scene.upload()
+    got = dev.intersect(rays)  # must come back (every lane's loop is bounded by the tree depth)
+    ref = orc.Scene(path).tree().intersect(rays, threads=8)
+    same = got.tobytes() == ref.tobytes()
+    if not same:  # NaN payloads may differ in sign/bits; indices and finite fields must not
+        assert (got["index"] == ref["index"]).all()
+        for k in ("t", "u", "v"):
+            a, b = got[k], ref[k]
+            assert ((a == b) | (np.isnan(a) & np.isnan(b))).all()
+    for i in np.flatnonzero(bad < 5)[:32]:
+        h = kd.intersect_host(o[i], d[i], (0.0, float(rays["tmax"][i])))
+        assert h["index"] == got["index"][i]
+    dev.close()
+
+
+def test_argument_errors():
+    scene = pt.LoadedScene(os.path.join(SCENES, "cornell.obj"))
+    dev = scene.upload()
+    with pytest.raises(pt.PtxError):
+        dev.set_pipelines(0)
+    with pytest.raises(pt.PtxError):
+        dev.set_pipelines(9)
+    with pytest.raises(pt.PtxError):
+        dev.set_queue_slots(1 << 29)
+    ph = scene.pinhole(16, 16)
+    assert not dev.render(ph, 0).any()  # zero samples: nothing added
+    with pytest.raises(pt.PtxError):
+        dev.render_device(ph, 1, 0)  # null accumulation buffer
+    bare = scene.kdtree().upload()  # no shading data
+    with pytest.raises(pt.PtxError):
+        bare.render(ph, 1)
+    bare.close()
+    dev.close()
