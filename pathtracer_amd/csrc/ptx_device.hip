@@ -1,16 +1,18 @@
 // ptx_device.hip — gfx950 kernels and the device half of the C ABI (include/ptx.h).
 //
-// Wavefront path tracer: generate → [extend → shade → shadow] × max_bounces → accumulate.
-//   generate    one path per (pixel, sample) slot: jittered pinhole ray        pathtracer.rs:113-117, camera.rs:88-93
-//   extend      nearest hit through the flattened KD-tree                       kdtree/src/lib.rs:73-132
-//   shade       everything between the two intersect calls of trace_ray         pathtracer.rs:44-108, material.rs:167-191,
-//               + next-ray emission and shadow-ray emission (queues compacted     light.rs:61-76, properties.rs:24-31
-//               with wave ballot + LDS prefix sum, one atomic per workgroup)
-//   shadow      occlusion of the light samples, radiance += T * sum(c_l)        pathtracer.rs:68-86
-//   accumulate  image += per-path radiance, samples added in index order        pathtracer.rs:138-140
-// A path's radiance is owned by its slot (no float atomics anywhere), so an image is bit-reproducible
-// and independent of queue order.  All arithmetic is IEEE f32 without contraction; random numbers and
+// Wavefront path tracer: start → [extend → shade → shadow → resolve] × rounds → accumulate.
+//   start       the first paths of every queue segment: jittered pinhole ray     pathtracer.rs:113-117, camera.rs:88-93
+//   extend      nearest hit through the KD-tree (k_traverse<false>)              kdtree/src/lib.rs:73-132
+//   shade       everything between the two intersect calls of trace_ray          pathtracer.rs:44-108, material.rs:167-191,
+//               + next-ray and shadow-ray emission, compacted per queue segment    light.rs:61-76, properties.rs:24-31
+//               (wave ballot + LDS prefix, no atomics), + path regeneration
+//   shadow      occlusion of the light samples (k_traverse<true>, any hit)       pathtracer.rs:72-78
+//   resolve     radiance += T * sum of the unoccluded contributions              pathtracer.rs:68-86
+//   accumulate  image += per-path radiance, samples added in index order         pathtracer.rs:138-140
+// A path's radiance is owned by its path id (no float atomics anywhere) and the queue order is deterministic,
+// so an image is bit-reproducible.  All arithmetic is IEEE f32 without contraction; random numbers and
 // sin/cos come from include/ptx_sampling.h.
+// Layout of this file: helpers, k_traverse, shading kernels, host-side state (ptx_scene), the entry points.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -68,7 +70,7 @@ struct RenderState {
     float4* sh_contrib;  // [i * n_lights + l] {bsdf * emitted * |cos|, 0}
     uint8_t* sh_occ;     // [i * n_lights + l] 1 = occluded
     // Queues are SEGMENTED: segment s owns slots [s * seg_cap, (s + 1) * seg_cap) of every queue for the
-    // whole batch; k_generate fills the segments in path order, and workgroup s of k_shade / k_resolve reads
+    // whole batch; k_start fills the segments in path order, and workgroup s of k_shade / k_resolve reads
     // segment s and compacts its survivors to the front of segment s of the output queue with a counter of
     // its own.  No global atomic sits on the path of a queue write (a single hot counter line serialises at
     // ~12 ns per workgroup: it was what bound k_shade), and the queue order is deterministic.
