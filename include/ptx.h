@@ -129,6 +129,7 @@ typedef struct ptx_scene ptx_scene; /* opaque: device-resident scene (one GPU) *
 
 #define PTX_FLAG_COUNT_WORK 1u   /* count node visits / triangle tests in the traversal kernels */
 #define PTX_FLAG_TIME_KERNELS 2u /* bracket each kernel class with HIP events inside ptx_render */
+#define PTX_FLAG_CHECK_BRUTE 4u  /* re-intersect every ray of ptx_render against all triangles (see ptx_check_report) */
 
 const char* ptx_last_error(void);
 const char* ptx_version(void);
@@ -255,6 +256,16 @@ int ptx_set_pipelines(ptx_scene* scene, uint32_t pipelines);
 int ptx_last_batch_counts(ptx_scene* scene, uint32_t* extend_counts, uint32_t* shadow_counts, uint32_t n);
 int ptx_stats(ptx_scene* scene, ptx_counters* out);
 int ptx_stats_reset(ptx_scene* scene);
+
+/* `kdtree-tester-cli test` on the GPU (kdtree-tester-cli/src/ray_tester.rs, ray_bouncer.rs:35-56): a scene
+ * created with PTX_FLAG_CHECK_BRUTE intersects every extend and shadow ray of ptx_render a second time
+ * against all triangles in index order (`intersect_closest_geometry`) and compares the two answers with
+ * `CheckedIntersection::is_valid` (checked_intersection.rs:10-25: same index, |dt| < 1e-6, |du|,|dv| < 1e-5;
+ * shadow rays: same yes/no).  ptx_check_report: rays checked / disagreements since the last ptx_stats_reset.
+ * ptx_check_fail_log: the first disagreements (at most 65536) as the 50-byte records of
+ * `CheckedIntersection::as_bytes` (checked_intersection.rs:27-56), readable by pybits/visualize_fails.py. */
+int ptx_check_report(ptx_scene* scene, uint64_t* n_checked, uint64_t* n_fails);
+int ptx_check_fail_log(ptx_scene* scene, uint8_t* out, uint32_t cap_records, uint32_t* n_written);
 /* Diagnostic (scenes created with PTX_FLAG_COUNT_WORK; no counterpart in the reference): how the lanes of
  * the traversal kernels spent their loop iterations since the last reset.  out24[0..11] = extend,
  * out24[12..23] = shadow: wave iterations, lane-visits of the node step, wave iterations that ran the

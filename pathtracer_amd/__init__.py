@@ -25,6 +25,7 @@ FMAX = float(np.finfo(np.float32).max)
 MAX_LIGHTS = 8
 FLAG_COUNT_WORK = 1
 FLAG_TIME_KERNELS = 2
+FLAG_CHECK_BRUTE = 4
 
 
 class PtxError(RuntimeError):
@@ -140,6 +141,9 @@ def make_rays(origins, directions, tmin=0.0, tmax=FMAX):
     r["tmin"] = tmin
     r["tmax"] = tmax
     return r
+
+
+FAIL_DTYPE = np.dtype([("i", "<u2"), ("o", "<f4", 3), ("d", "<f4", 3), ("correct", "<f4", 3), ("actual", "<f4", 3)])  # pybits/visualize_fails.py
 
 
 class KdTree:
@@ -411,6 +415,19 @@ class DeviceScene:
 
     def stats_reset(self):
         _check(lib().ptx_stats_reset(self._h))
+
+    def check_report(self):
+        """(rays checked, disagreements) of a FLAG_CHECK_BRUTE scene: `kdtree-tester-cli test` on the GPU."""
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(lib().ptx_check_report(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def check_fail_log(self, cap=65536):
+        """The 50-byte fail records of checked_intersection.rs:27-56 as a structured array."""
+        raw = np.zeros(cap * 50, np.uint8)
+        n = C.c_uint32()
+        _check(lib().ptx_check_fail_log(self._h, _ptr(raw), cap, C.byref(n)))
+        return raw[: n.value * 50].view(FAIL_DTYPE)
 
     def loop_profile(self):
         """Diagnostic (FLAG_COUNT_WORK scenes): lane occupancy of the traversal loop, per kernel."""

@@ -791,6 +791,94 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(RenderState st, uint32_t boun
     }
 }
 
+// Checker (PTX_FLAG_CHECK_BRUTE): every ray of a queue again, against ALL triangles in index order
+// (`intersect_closest_geometry`, geometry/src/geometry.rs:176-196 — what kdtree-tester-cli calls the reference
+// intersection, ray_bouncer.rs:35-42), compared with what the KD-tree traversal answered under the tolerances
+// of `CheckedIntersection::is_valid` (kdtree-tester-cli/src/checked_intersection.rs:10-25).  Disagreements are
+// appended to a fail list.  One workgroup per queue segment; the triangles pass through LDS in tiles.
+struct FailRec {
+    float o[3], d[3];
+    float t_ref, t_kd;
+    uint32_t flags;  // bit 0: the reference hit something, bit 1: the kd-tree did, bit 2: shadow ray
+    uint32_t pad;
+};
+struct CheckArgs {
+    const TriRec* tris;
+    uint32_t n_tris;
+    const ptx_ray* rays;
+    const uint32_t* seg_counts;
+    uint32_t n_seg, seg_cap, scale;
+    uint32_t internal;      // extend queue: t in [0, f32::MAX]
+    const ptx_hit* hits;    // nearest-hit answers, or
+    const uint8_t* occ;     // occlusion answers
+    FailRec* fails;
+    uint32_t fail_cap;
+    unsigned long long* counters;  // [0] rays checked, [1] fails found
+};
+constexpr int CHECK_TILE = 256;
+
+__global__ __launch_bounds__(BLOCK) void k_check(CheckArgs c) {
+    __shared__ TriRec s_tris[CHECK_TILE];
+    for (uint32_t seg = blockIdx.x; seg < c.n_seg; seg += gridDim.x) {
+        const uint32_t count = c.seg_counts[seg] * c.scale;
+        const size_t base = (size_t)seg * c.seg_cap * c.scale;
+        for (uint32_t start = 0; start < count; start += BLOCK) {
+            const bool active = start + threadIdx.x < count;
+            const size_t i = base + start + threadIdx.x;
+            float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, t1 = 0, t2 = 0;
+            if (active) {
+                const float4 ra = reinterpret_cast<const float4*>(c.rays)[2 * i];
+                const float4 rb = reinterpret_cast<const float4*>(c.rays)[2 * i + 1];
+                ox = ra.x, oy = ra.y, oz = ra.z, t1 = c.internal ? 0.0f : ra.w;
+                dx = rb.x, dy = rb.y, dz = rb.z, t2 = c.internal ? 3.402823466e+38f : rb.w;
+            }
+            uint32_t bi = PTX_MISS;
+            float bt = 0.0f, bu = 0.0f, bv = 0.0f;
+            for (uint32_t tile = 0; tile < c.n_tris; tile += CHECK_TILE) {
+                __syncthreads();
+                for (uint32_t k = threadIdx.x; k < CHECK_TILE && tile + k < c.n_tris; k += BLOCK) s_tris[k] = c.tris[tile + k];
+                __syncthreads();
+                const uint32_t n = c.n_tris - tile < (uint32_t)CHECK_TILE ? c.n_tris - tile : (uint32_t)CHECK_TILE;
+                if (active) {
+                    for (uint32_t k = 0; k < n; ++k) {
+                        float t, u, v;
+                        if (tri_test(s_tris[k], ox, oy, oz, dx, dy, dz, t, u, v) && t1 <= t && t <= t2) {
+                            if (bi == PTX_MISS || !(bt <= t)) bt = t, bu = u, bv = v, bi = tile + k;  // IndexedIntersection::min
+                        }
+                    }
+                }
+            }
+            if (active) {
+                bool kd_some, valid;
+                float t_kd = 0.0f;
+                if (c.hits) {
+                    const uint4 h = reinterpret_cast<const uint4*>(c.hits)[i];
+                    kd_some = h.x != PTX_MISS;
+                    t_kd = u2f(h.y);
+                    valid = (!kd_some && bi == PTX_MISS) ||
+                            (kd_some && bi != PTX_MISS && h.x == bi && fabsf(bt - t_kd) < 0.000001f &&
+                             fabsf(bu - u2f(h.z)) < 0.00001f && fabsf(bv - u2f(h.w)) < 0.00001f);
+                } else {
+                    kd_some = c.occ[i] != 0;  // the shadow query only knows yes / no
+                    valid = kd_some == (bi != PTX_MISS);
+                }
+                if (!valid) {
+                    const unsigned long long at = atomicAdd(&c.counters[1], 1ull);
+                    if (at < c.fail_cap) {
+                        FailRec r;
+                        r.o[0] = ox, r.o[1] = oy, r.o[2] = oz, r.d[0] = dx, r.d[1] = dy, r.d[2] = dz;
+                        r.t_ref = bt, r.t_kd = t_kd;
+                        r.flags = (bi != PTX_MISS ? 1u : 0u) | (kd_some ? 2u : 0u) | (c.hits ? 0u : 4u);
+                        r.pad = 0;
+                        c.fails[at] = r;
+                    }
+                }
+            }
+        }
+        if (threadIdx.x == 0 && count) atomicAdd(&c.counters[0], (unsigned long long)count);
+    }
+}
+
 // `*value += render_pixel(..)` (pathtracer.rs:138-140), samples added in index order.
 __global__ __launch_bounds__(BLOCK) void k_accumulate(RenderState st, float* __restrict__ accum) {
     for (uint32_t pixel = blockIdx.x * BLOCK + threadIdx.x; pixel < st.n_pixels; pixel += gridDim.x * BLOCK) {
@@ -920,6 +1008,9 @@ struct ptx_scene {
     DevBuf<uint2> spill;  // of the *_batch entry points
     DevBuf<uint32_t> batch_cursor;
     DevBuf<unsigned long long> totals;
+    DevBuf<FailRec> fails;                   // PTX_FLAG_CHECK_BRUTE
+    DevBuf<unsigned long long> check_count;  // [2] rays checked, fails found
+    static constexpr uint32_t FAIL_CAP = 1u << 16;
     uint64_t samples_done = 0;
     uint64_t batch_extend_rays = 0, batch_shadow_rays = 0;  // rays of the *_batch entry points
     uint64_t extend_launches = 0, shadow_launches = 0;
@@ -1166,6 +1257,25 @@ int launch_traverse(ptx_scene* sc, const ptx_ray* d_rays, const SegRange& sr, ui
     return PTX_OK;
 }
 
+void launch_check(ptx_scene* sc, const ptx_ray* rays, const SegRange& sr, const ptx_hit* hits, const uint8_t* occ,
+                  hipStream_t stream) {
+    CheckArgs c{};
+    c.tris = sc->dev.tris;
+    c.n_tris = sc->n_triangles;
+    c.rays = rays;
+    c.seg_counts = sr.counts;
+    c.n_seg = sr.n_seg;
+    c.seg_cap = sr.cap;
+    c.scale = sr.scale;
+    c.internal = sr.internal ? 1u : 0u;
+    c.hits = hits;
+    c.occ = occ;
+    c.fails = sc->fails.p;
+    c.fail_cap = ptx_scene::FAIL_CAP;
+    c.counters = sc->check_count.p;
+    k_check<<<(int)sr.n_seg, BLOCK, 0, stream>>>(c);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1290,6 +1400,11 @@ int ptx_scene_create(const ptx_scene_desc* d, uint32_t flags, ptx_scene** out) {
     HIP_TRY(hipMemset(sc->totals.p, 0, 32 * sizeof(unsigned long long)));
     HIP_TRY(sc->spill.ensure((size_t)(PTX_MAX_DEPTH - LDS_DEPTH) * sc->tgrid * TBLOCK));
     HIP_TRY(sc->batch_cursor.ensure(1));
+    if (flags & PTX_FLAG_CHECK_BRUTE) {
+        HIP_TRY(sc->fails.ensure(ptx_scene::FAIL_CAP));
+        HIP_TRY(sc->check_count.ensure(2));
+        HIP_TRY(hipMemset(sc->check_count.p, 0, 2 * sizeof(unsigned long long)));
+    }
     *out = sc.release();
     return PTX_OK;
 }
@@ -1487,6 +1602,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
                 rc = launch_traverse<false>(sc, st.rays[(b - 1) & 1], sr, 0, st.hits, nullptr, st.cursors + 2 * (b - 1),
                                             p.spill.p, sc->totals.p + 2, stream);
                 if (rc) return rc;
+                if (sc->flags & PTX_FLAG_CHECK_BRUTE) launch_check(sc, st.rays[(b - 1) & 1], sr, st.hits, nullptr, stream);
             }
             // k_shade(b) reuses the shadow queue and adds to the radiance: after resolve(b-1)
             if (overlap && b > 1) HIP_TRY(hipStreamWaitEvent(stream, p.ev_resolve, 0));
@@ -1515,6 +1631,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
                     rc = launch_traverse<true>(sc, st.sh_rays, sr, 0, nullptr, st.sh_occ, st.cursors + 2 * (b - 1) + 1, sspill,
                                                sc->totals.p + 4, sstream);
                     if (rc) return rc;
+                    if (sc->flags & PTX_FLAG_CHECK_BRUTE) launch_check(sc, st.sh_rays, sr, nullptr, st.sh_occ, sstream);
                 }
                 {
                     Timed tm(sc, sstream, KC_OTHER);
@@ -1627,6 +1744,48 @@ int ptx_debug_loop_profile(ptx_scene* sc, uint64_t* out24) {
     return PTX_OK;
 }
 
+int ptx_check_report(ptx_scene* sc, uint64_t* n_checked, uint64_t* n_fails) {
+    int rc = check_scene(sc, "ptx_check_report");
+    if (rc) return rc;
+    if (!(sc->flags & PTX_FLAG_CHECK_BRUTE)) return fail(PTX_E_ARG, "ptx_check_report: scene was created without PTX_FLAG_CHECK_BRUTE");
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long c[2] = {0, 0};
+    HIP_TRY(hipMemcpy(c, sc->check_count.p, sizeof c, hipMemcpyDeviceToHost));
+    if (n_checked) *n_checked = c[0];
+    if (n_fails) *n_fails = c[1];
+    return PTX_OK;
+}
+
+int ptx_check_fail_log(ptx_scene* sc, uint8_t* out, uint32_t cap_records, uint32_t* n_written) {
+    uint64_t n_fails = 0;
+    int rc = ptx_check_report(sc, nullptr, &n_fails);
+    if (rc) return rc;
+    if ((!out && cap_records) || !n_written) return fail(PTX_E_ARG, "ptx_check_fail_log: null argument");
+    uint32_t n = (uint32_t)(n_fails < ptx_scene::FAIL_CAP ? n_fails : ptx_scene::FAIL_CAP);
+    if (n > cap_records) n = cap_records;
+    std::vector<FailRec> recs(n);
+    if (n) HIP_TRY(hipMemcpy(recs.data(), sc->fails.p, (size_t)n * sizeof(FailRec), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i) {  // CheckedIntersection::as_bytes, checked_intersection.rs:27-56
+        const FailRec& r = recs[i];
+        const bool ref_some = (r.flags & 1u) != 0, kd_some = (r.flags & 2u) != 0 && !(r.flags & 4u);
+        const float t_ext = kd_some ? r.t_kd : (ref_some ? r.t_ref : 1.0f);  // Ray::extended(t)
+        const bool extend = kd_some || ref_some;
+        float f[12];
+        for (int k = 0; k < 3; ++k) {
+            f[k] = r.o[k];
+            f[3 + k] = extend ? t_ext * r.d[k] : r.d[k];
+            f[6 + k] = ref_some ? r.o[k] + r.t_ref * r.d[k] : 0.0f;  // (the reference unwraps here)
+            f[9 + k] = kd_some ? r.o[k] + r.t_kd * r.d[k] : 0.0f;
+        }
+        uint8_t* b = out + 50 * (size_t)i;
+        const uint16_t it = (uint16_t)i;
+        memcpy(b, &it, 2);
+        memcpy(b + 2, f, 48);
+    }
+    *n_written = n;
+    return PTX_OK;
+}
+
 int ptx_stats_reset(ptx_scene* sc) {
     int rc = check_scene(sc, "ptx_stats_reset");
     if (rc) return rc;
@@ -1637,6 +1796,7 @@ int ptx_stats_reset(ptx_scene* sc) {
     sc->total_ms = 0;
     sc->samples_done = 0;
     sc->batch_extend_rays = sc->batch_shadow_rays = 0;
+    if (sc->check_count.p) HIP_TRY(hipMemset(sc->check_count.p, 0, 2 * sizeof(unsigned long long)));
     sc->extend_launches = sc->shadow_launches = 0;
     return PTX_OK;
 }
