@@ -241,6 +241,13 @@ int ptx_render_device(ptx_scene* scene, const ptx_pinhole* camera, uint64_t seed
                       uint32_t sample_count, float* d_accum, void* stream);
 /* Samples kept in flight per launch batch (default chosen from the image size). */
 int ptx_set_batch_samples(ptx_scene* scene, uint32_t samples_per_batch);
+/* `Pathtracer::render_subdivided_mut` (tracing/src/pathtracer.rs:143-161, driven by
+ * worker.rs:52-82 `render_parallel_subdivided`): adds the samples of the pixels of one rectangle only, into the
+ * full-size width*height*3 buffer.  A pixel's samples do not depend on the tiling (the sampler is keyed by the
+ * image pixel), so tiles rendered in any order add up to exactly what ptx_render_device gives. */
+int ptx_render_region_device(ptx_scene* scene, const ptx_pinhole* camera, uint32_t x, uint32_t y, uint32_t width,
+                             uint32_t height, uint64_t seed, uint32_t first_sample, uint32_t sample_count,
+                             float* d_accum, void* stream);
 /* Queue slots (paths in flight) over all pipelines; 0 = default (320 Mi, ~67 GB).  A batch with more paths
  * than slots is rendered with path regeneration: finished paths are replaced by the next camera rays of the
  * batch, so the memory stays bounded while every launch stays wide.  Results do not depend on it. */

@@ -401,6 +401,11 @@ class DeviceScene:
         _check(lib().ptx_render_device(self._h, C.byref(pinhole), C.c_uint64(seed), first_sample, sample_count,
                                        C.c_void_p(d_accum_ptr), C.c_void_p(stream)))
 
+    def render_region_device(self, pinhole, x, y, width, height, sample_count, d_accum_ptr, seed=0, first_sample=0, stream=None):
+        """`render_subdivided_mut`: the samples of one rectangle of the image only."""
+        _check(lib().ptx_render_region_device(self._h, C.byref(pinhole), x, y, width, height, C.c_uint64(seed), first_sample,
+                                              sample_count, C.c_void_p(d_accum_ptr), C.c_void_p(stream)))
+
     def stats(self):
         c = Counters()
         _check(lib().ptx_stats(self._h, C.byref(c)))

@@ -92,7 +92,8 @@ struct RenderState {
     unsigned long long* totals;  // extend rays, shadow rays, ext inner, ext tris, sh inner, sh tris
     ptx_pinhole cam;
     uint64_t seed;
-    uint32_t n_pixels, n_samples, first_sample;
+    uint32_t n_pixels, n_samples, first_sample;  // n_pixels = pixels of the rendered region
+    uint32_t reg_x, reg_y, reg_w;                // the region's corner and width inside the cam.width x cam.height image
 };
 
 // ------------------------------------------------------------------------------------------ helpers
@@ -472,11 +473,16 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
     }
 }
 
+// Image pixel (row-major index into the full image) of the region's local pixel number.
+__device__ inline uint32_t image_pixel(const RenderState& st, uint32_t local) {
+    return (st.reg_y + local / st.reg_w) * st.cam.width + st.reg_x + local % st.reg_w;
+}
+
 // sample_ray_for_pixel (pathtracer.rs:113-117) + Pinhole::ray (camera.rs:88-93): starts path `pid` in queue
 // slot `slot` and resets its state.
 __device__ inline void start_path(const RenderState& st, ptx_ray* __restrict__ rays, float4* __restrict__ trans, uint32_t slot,
                                   uint32_t pid) {
-    const uint32_t pixel = pid % st.n_pixels, s = pid / st.n_pixels;
+    const uint32_t pixel = image_pixel(st, pid % st.n_pixels), s = pid / st.n_pixels;
     const uint32_t px = pixel % st.cam.width, py = pixel / st.cam.width;
     const uint64_t key = ptx_path_key(st.seed, pixel, st.first_sample + s);
     const float cx = (float)px + ptx_u01(key, 0), cy = (float)py + ptx_u01(key, 1);
@@ -674,7 +680,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, ui
                 const V3 point = ro + ht * rd;
                 point_above = point + offset;
                 const V3 point_below = point - offset;
-                const uint32_t pixel = pid % st.n_pixels, s = pid / st.n_pixels;
+                const uint32_t pixel = image_pixel(st, pid % st.n_pixels), s = pid / st.n_pixels;
                 const uint64_t key = ptx_path_key(st.seed, pixel, st.first_sample + s);
                 const Bsdf smp = material_sample(mat, wi, n, uvx, uvy, key, base);
 
@@ -881,10 +887,11 @@ __global__ __launch_bounds__(BLOCK) void k_check(CheckArgs c) {
 
 // `*value += render_pixel(..)` (pathtracer.rs:138-140), samples added in index order.
 __global__ __launch_bounds__(BLOCK) void k_accumulate(RenderState st, float* __restrict__ accum) {
-    for (uint32_t pixel = blockIdx.x * BLOCK + threadIdx.x; pixel < st.n_pixels; pixel += gridDim.x * BLOCK) {
+    for (uint32_t local = blockIdx.x * BLOCK + threadIdx.x; local < st.n_pixels; local += gridDim.x * BLOCK) {
+        const uint32_t pixel = image_pixel(st, local);
         float r = accum[3 * (size_t)pixel], g = accum[3 * (size_t)pixel + 1], b = accum[3 * (size_t)pixel + 2];
         for (uint32_t s = 0; s < st.n_samples; ++s) {
-            const float4 v = st.radiance[(size_t)s * st.n_pixels + pixel];
+            const float4 v = st.radiance[(size_t)s * st.n_pixels + local];
             r += v.x;
             g += v.y;
             b += v.z;
@@ -1484,14 +1491,21 @@ int ptx_set_pipelines(ptx_scene* sc, uint32_t n) {
     return PTX_OK;
 }
 
+struct Region {
+    uint32_t x, y, w, h;
+};
+
 static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uint32_t first_sample,
                        uint32_t sample_count, float* d_accum, hipStream_t user_stream, ptx_progress_cb progress,
-                       void* user) {
+                       void* user, const Region* region = nullptr) {
     if (!cam || !d_accum) return fail(PTX_E_ARG, "ptx_render: null argument");
     if (!sc->shading) return fail(PTX_E_ARG, "ptx_render: scene was created without shading data");
     if (cam->width == 0 || cam->height == 0) return fail(PTX_E_ARG, "ptx_render: empty image");
-    const uint64_t n_pixels64 = (uint64_t)cam->width * cam->height;
-    if (n_pixels64 > (1ull << 27)) return fail(PTX_E_LIMIT, "ptx_render: image larger than 2^27 pixels");
+    if ((uint64_t)cam->width * cam->height > (1ull << 27)) return fail(PTX_E_LIMIT, "ptx_render: image larger than 2^27 pixels");
+    const Region reg = region ? *region : Region{0u, 0u, cam->width, cam->height};
+    if (reg.w == 0 || reg.h == 0 || (uint64_t)reg.x + reg.w > cam->width || (uint64_t)reg.y + reg.h > cam->height)
+        return fail(PTX_E_ARG, "ptx_render_region: the region is empty or reaches outside the image");
+    const uint64_t n_pixels64 = (uint64_t)reg.w * reg.h;
     if ((uint64_t)first_sample + sample_count > 0xFFFFFFFFull) return fail(PTX_E_LIMIT, "ptx_render: sample index overflow");
     const uint32_t n_pixels = (uint32_t)n_pixels64;
     // Batches.  The last rays of a launch finish ~0.3 ms after its cursor drains, and the late bounces of a
@@ -1576,6 +1590,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         st.cam = *cam;
         st.seed = seed;
         st.n_pixels = n_pixels;
+        st.reg_x = reg.x, st.reg_y = reg.y, st.reg_w = reg.w;
         st.n_samples = ns;
         st.n_paths = ns * n_pixels;
         st.first_sample = first_sample + done;
@@ -1671,6 +1686,14 @@ int ptx_render_device(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uint
     int rc = check_scene(sc, "ptx_render_device");
     if (rc) return rc;
     return render_impl(sc, cam, seed, first_sample, sample_count, d_accum, (hipStream_t)stream, nullptr, nullptr);
+}
+
+int ptx_render_region_device(ptx_scene* sc, const ptx_pinhole* cam, uint32_t x, uint32_t y, uint32_t width, uint32_t height,
+                             uint64_t seed, uint32_t first_sample, uint32_t sample_count, float* d_accum, void* stream) {
+    int rc = check_scene(sc, "ptx_render_region_device");
+    if (rc) return rc;
+    const Region reg{x, y, width, height};
+    return render_impl(sc, cam, seed, first_sample, sample_count, d_accum, (hipStream_t)stream, nullptr, nullptr, &reg);
 }
 
 int ptx_render(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uint32_t first_sample, uint32_t sample_count,

@@ -150,3 +150,33 @@ def test_argument_errors():
         bare.render(ph, 1)
     bare.close()
     dev.close()
+
+
+def test_tiles_add_up_to_the_full_frame():
+    """`render_subdivided_mut` (pathtracer.rs:143-161): ragged tiles in shuffled order == one full-frame call."""
+    import torch
+
+    scene = pt.LoadedScene(os.path.join(SCENES, "cornell_textured.obj"), max_bounces=6)
+    dev = scene.upload()
+    w, h, spp = 70, 45, 3
+    ph = scene.pinhole(w, h)
+    stream = torch.cuda.current_stream().cuda_stream
+    full = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
+    dev.render_device(ph, spp, full.data_ptr(), seed=21, first_sample=4, stream=stream)
+    tiled = torch.zeros_like(full)
+    tiles = [(x, y, min(32, w - x), min(16, h - y)) for y in range(0, h, 16) for x in range(0, w, 32)]
+    for k in np.random.default_rng(0).permutation(len(tiles)):
+        x, y, tw, th = tiles[k]
+        dev.render_region_device(ph, x, y, tw, th, spp, tiled.data_ptr(), seed=21, first_sample=4, stream=stream)
+    torch.cuda.synchronize()
+    assert torch.equal(full, tiled)
+    # a one-pixel region touches one pixel
+    one = torch.zeros_like(full)
+    dev.render_region_device(ph, 69, 44, 1, 1, spp, one.data_ptr(), seed=21, first_sample=4, stream=stream)
+    torch.cuda.synchronize()
+    img = one.cpu().numpy().reshape(h, w, 3)
+    assert img[44, 69].tobytes() == full.cpu().numpy().reshape(h, w, 3)[44, 69].tobytes() and not img[:44].any() and not img[44, :69].any()
+    for bad in ((0, 0, 0, 5), (60, 0, 11, 5), (0, 45, 1, 1)):
+        with pytest.raises(pt.PtxError):
+            dev.render_region_device(ph, *bad, 1, one.data_ptr(), stream=stream)
+    dev.close()
