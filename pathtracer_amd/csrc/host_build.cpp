@@ -9,6 +9,8 @@
 //   kdtree/src/event.rs:46-96   event order = (f32 total order of distance, kind)
 // Output layout: include/ptx.h `ptx_kdnode`.
 #include <algorithm>
+#include <thread>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/ptx.h"
@@ -228,6 +230,54 @@ struct Builder {
         nodes[me].w1 = ((uint32_t)nodes.size() << 2) | (uint32_t)p.axis;
         grow(R, depth + 1);
     }
+
+    // The same tree, built by several threads: the two subtrees of a node share nothing but the (read-only)
+    // triangles, so above `par_levels` the left one is grown by another thread into arrays of its own and
+    // spliced in afterwards (child and leaf offsets shifted).  Decisions, node order and leaf order are those
+    // of grow(): the result is identical bit for bit.
+    void append(const Builder& sub) {
+        const uint32_t node_at = (uint32_t)nodes.size(), leaf_at = (uint32_t)leaves.size();
+        for (const ptx_kdnode& nd : sub.nodes) {
+            if ((nd.w1 & 3u) == 3u) nodes.push_back({nd.w0 + leaf_at, nd.w1});
+            else nodes.push_back({nd.w0, (((nd.w1 >> 2) + node_at) << 2) | (nd.w1 & 3u)});
+        }
+        leaves.insert(leaves.end(), sub.leaves.begin(), sub.leaves.end());
+    }
+
+    Builder child() const {
+        Builder b;
+        b.tris = tris;
+        b.n = n;
+        b.sah = sah;
+        b.side.assign(n, SIDE_BOTH);
+        return b;
+    }
+
+    void grow_parallel(Cell& c, uint32_t depth, int par_levels) {
+        if (par_levels <= 0 || c.ids.size() < 512 || depth >= PTX_MAX_DEPTH) {
+            grow(c, depth);
+            return;
+        }
+        Plane p = choose(c);
+        if (!p.valid) {
+            emit_leaf(c.ids);
+            return;
+        }
+        Cell L, R;
+        split(c, p, L, R);
+        c = Cell();
+        Builder left = child(), right = child();
+        std::thread worker([&] { left.grow_parallel(L, depth + 1, par_levels - 1); });
+        right.grow_parallel(R, depth + 1, par_levels - 1);
+        worker.join();
+        const size_t me = nodes.size();
+        uint32_t bits;
+        std::memcpy(&bits, &p.d, 4);
+        nodes.push_back({bits, (uint32_t)p.axis});
+        append(left);
+        nodes[me].w1 = ((uint32_t)nodes.size() << 2) | (uint32_t)p.axis;
+        append(right);
+    }
 };
 
 }  // namespace
@@ -270,7 +320,15 @@ void build_flat_kdtree(const float* tris, uint32_t n, const ptx_sah_cost& sah,
     }
     if (first) root.box = {f3(0, 0, 0), f3(0, 0, 0)};
     for (int a = 0; a < 3; ++a) std::sort(root.ev[a].begin(), root.ev[a].end(), ev_before);
-    b.grow(root, 1);
+    // 2^4 = 16 subtrees in flight at most (PTX_BUILD_THREADS=1 builds on the calling thread alone)
+    int par_levels = 4;
+    if (const char* e = getenv("PTX_BUILD_THREADS")) {
+        const int t = atoi(e);
+        par_levels = t <= 1 ? 0 : (t <= 2 ? 1 : (t <= 4 ? 2 : (t <= 8 ? 3 : 4)));
+    }
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw && hw < 4) par_levels = hw < 2 ? 0 : 1;
+    b.grow_parallel(root, 1, par_levels);
     nodes.swap(b.nodes);
     leaves.swap(b.leaves);
 }

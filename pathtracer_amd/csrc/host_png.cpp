@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "host_internal.hpp"
@@ -50,9 +51,43 @@ int ptx_png_write_rgb8(const char* path, const uint8_t* rgb, uint32_t width, uin
         raw.push_back(0);  // filter: none
         raw.insert(raw.end(), rgb + (size_t)y * width * 3, rgb + (size_t)(y + 1) * width * 3);
     }
-    uLongf zn = compressBound((uLong)raw.size());
-    std::vector<uint8_t> z(zn);
-    if (compress2(z.data(), &zn, raw.data(), (uLong)raw.size(), 6) != Z_OK) return fail(PTX_E_IO, "zlib compress failed");
+    // One zlib stream assembled from independently deflated stripes (raw deflate, each but the last ended with
+    // a sync flush so that the pieces concatenate), the way pigz does: the stripes compress in parallel.
+    unsigned workers = std::thread::hardware_concurrency();
+    workers = workers > 16 ? 16 : (workers < 1 ? 1 : workers);
+    size_t n_stripes = raw.size() / (256u << 10);  // at least 256 KiB per stripe
+    n_stripes = n_stripes < 1 ? 1 : (n_stripes > workers ? workers : n_stripes);
+    const size_t stripe = (raw.size() + n_stripes - 1) / n_stripes;
+    std::vector<std::vector<uint8_t>> parts(n_stripes);
+    std::vector<int> ok(n_stripes, 0);
+    auto deflate_stripe = [&](size_t k) {
+        const size_t lo = k * stripe, hi = lo + stripe < raw.size() ? lo + stripe : raw.size();
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return;
+        parts[k].resize(deflateBound(&zs, (uLong)(hi - lo)) + 16);
+        zs.next_in = const_cast<Bytef*>(raw.data() + lo);
+        zs.avail_in = (uInt)(hi - lo);
+        zs.next_out = parts[k].data();
+        zs.avail_out = (uInt)parts[k].size();
+        const int rc = deflate(&zs, k + 1 == n_stripes ? Z_FINISH : Z_SYNC_FLUSH);
+        ok[k] = (k + 1 == n_stripes ? rc == Z_STREAM_END : rc == Z_OK) && zs.avail_in == 0;
+        parts[k].resize(zs.total_out);
+        deflateEnd(&zs);
+    };
+    {
+        std::vector<std::thread> pool;
+        for (size_t k = 1; k < n_stripes; ++k) pool.emplace_back(deflate_stripe, k);
+        deflate_stripe(0);
+        for (auto& t : pool) t.join();
+    }
+    for (int good : ok)
+        if (!good) return fail(PTX_E_IO, "zlib deflate failed");
+    std::vector<uint8_t> z = {0x78, 0x9C};  // zlib header: deflate, 32 KiB window, default level
+    for (auto& part : parts) z.insert(z.end(), part.begin(), part.end());
+    const uLong adler = adler32(adler32(0L, Z_NULL, 0), raw.data(), (uInt)raw.size());
+    put32(z, (uint32_t)adler);
+    uLongf zn = (uLongf)z.size();
     std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
     std::vector<uint8_t> ihdr;
     put32(ihdr, width);

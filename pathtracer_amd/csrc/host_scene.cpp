@@ -17,6 +17,7 @@
 #include <map>
 #include <memory>
 #include <sstream>
+#include <thread>
 #include <stdexcept>
 
 #include "host_geom.hpp"
@@ -329,11 +330,27 @@ int ptx_tonemap_rgb8(const float* accum, uint32_t width, uint32_t height, uint32
     const uint16_t iters = (uint16_t)iterations;  // `total_iterations as u16` (worker.rs:113)
     const float inv = 1.0f / (float)iters;
     const size_t n = (size_t)width * height * 3;
-    for (size_t i = 0; i < n; ++i) {
-        float g = std::pow(accum[i] * inv, 1.0f / 2.2f);
-        g = g < 1.0f ? g : 1.0f;
-        float c = std::round(g * 255.0f);
-        out[i] = !(c == c) ? 0 : (c <= 0.0f ? 0 : (c >= 255.0f ? 255 : (uint8_t)c));
+    auto span = [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            float g = std::pow(accum[i] * inv, 1.0f / 2.2f);
+            g = g < 1.0f ? g : 1.0f;
+            float c = std::round(g * 255.0f);
+            out[i] = !(c == c) ? 0 : (c <= 0.0f ? 0 : (c >= 255.0f ? 255 : (uint8_t)c));
+        }
+    };
+    // every value is independent: slices on a few threads (the powf dominates; 3.5 M of them at 1080^2)
+    unsigned workers = std::thread::hardware_concurrency();
+    workers = workers > 16 ? 16 : (workers < 1 ? 1 : workers);
+    if (n < (1u << 16) || workers == 1) {
+        span(0, n);
+    } else {
+        std::vector<std::thread> pool;
+        const size_t step = (n + workers - 1) / workers;
+        for (unsigned w = 0; w < workers; ++w) {
+            const size_t lo = (size_t)w * step, hi = lo + step < n ? lo + step : n;
+            if (lo < hi) pool.emplace_back(span, lo, hi);
+        }
+        for (auto& t : pool) t.join();
     }
     return PTX_OK;
 }

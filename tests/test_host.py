@@ -195,3 +195,16 @@ def test_device_calls_fail_loudly_without_a_gpu():
     with pytest.raises(pt.PtxError) as e:
         t.upload()
     assert e.value.code == -2  # PTX_E_HIP: no fallback
+
+
+def test_serial_and_parallel_builds_are_the_same_tree():
+    """the builder grows the top subtrees on several threads; PTX_BUILD_THREADS=1 keeps it on one."""
+    import subprocess
+    import sys
+
+    code = ("import sys, hashlib; sys.path.insert(0, %r); import pathtracer_amd as pt; "
+            "kd = pt.LoadedScene(%r).kdtree(); print(hashlib.sha256(kd.nodes.tobytes() + kd.leaf_indices.tobytes()).hexdigest())"
+            % (ROOT, os.path.join(ROOT, "scenes", "cornell_teapot.obj")))
+    digests = {subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PTX_BUILD_THREADS=t), capture_output=True, text=True,
+                              check=True).stdout.strip() for t in ("1", "2", "16")}
+    assert len(digests) == 1 and len(digests.pop()) == 64
