@@ -239,7 +239,8 @@ int ptx_render(ptx_scene* scene, const ptx_pinhole* camera, uint64_t seed, uint3
  * multi-GPU driver calls before its RCCL reduce of the per-GPU buffers. */
 int ptx_render_device(ptx_scene* scene, const ptx_pinhole* camera, uint64_t seed, uint32_t first_sample,
                       uint32_t sample_count, float* d_accum, void* stream);
-/* Samples kept in flight per launch batch (default chosen from the image size). */
+/* Samples per batch (0 = as many as the path-id and queue-slot budgets allow: one batch if possible).  A batch
+ * is rendered as one sequence of rounds over its own queues; results do not depend on the batching. */
 int ptx_set_batch_samples(ptx_scene* scene, uint32_t samples_per_batch);
 /* `Pathtracer::render_subdivided_mut` (tracing/src/pathtracer.rs:143-161, driven by
  * worker.rs:52-82 `render_parallel_subdivided`): adds the samples of the pixels of one rectangle only, into the
