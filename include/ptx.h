@@ -274,6 +274,17 @@ int ptx_stats_reset(ptx_scene* scene);
  * `CheckedIntersection::as_bytes` (checked_intersection.rs:27-56), readable by pybits/visualize_fails.py. */
 int ptx_check_report(ptx_scene* scene, uint64_t* n_checked, uint64_t* n_fails);
 int ptx_check_fail_log(ptx_scene* scene, uint8_t* out, uint32_t cap_records, uint32_t* n_written);
+/* Ray log (tracing/src/raylogger.rs:9-72, written from pathtracer.rs:34-43 and 69-71 when the reference is
+ * built with its `ray_logging` feature; worker.rs:18-25 names the files ./tmp/raylog{thread}.bin).
+ * ptx_raylog_enable(max_records > 0) makes every following render append one record per extend ray - stretched
+ * to its hit point (`ray.extended(t)`) when it hit - and per shadow ray, up to max_records (32 bytes of device
+ * memory each); 0 switches the log off.  ptx_raylog_read hands out what was logged since the last read as the
+ * reference's 33-byte records {iteration u16, pixel_x u16, pixel_y u16, bounces u8, shadow u8, intersect u8,
+ * origin 3 x f32, direction 3 x f32} (raylogger.rs:54-66, little endian), in the order one reference thread
+ * writes them (iteration = sample index, then pixel rows, columns, the path's bounces, extend ray before its
+ * shadow rays), and empties the log.  n_dropped = records that did not fit max_records or cap_records. */
+int ptx_raylog_enable(ptx_scene* scene, uint64_t max_records);
+int ptx_raylog_read(ptx_scene* scene, uint8_t* out, uint64_t cap_records, uint64_t* n_written, uint64_t* n_dropped);
 /* Diagnostic (scenes created with PTX_FLAG_COUNT_WORK; no counterpart in the reference): how the lanes of
  * the traversal kernels spent their loop iterations since the last reset.  out24[0..11] = extend,
  * out24[12..23] = shadow: wave iterations, lane-visits of the node step, wave iterations that ran the

@@ -729,4 +729,51 @@ size_t orc_bounce_rays(void* hh, uint32_t w, uint32_t h, uint32_t bounces, uint6
     return total;
 }
 
+
+// The reference's ray log (raylogger.rs:39-66; pathtracer.rs:34-43, 69-71; worker.rs:36-47): what ONE thread
+// rendering iterations first_sample .. first_sample+count-1 with the COUNTER sampler writes to its
+// raylog file, 33 bytes per ray.  Returns the number of records; only the first cap are stored.
+size_t orc_render_raylog(void* hh, uint32_t w, uint32_t h, uint64_t seed, uint32_t first_sample, uint32_t count,
+                         uint8_t* out, size_t cap) {
+    SceneH* s = (SceneH*)hh;
+    const Scene& sc = s->scene;
+    Pinhole cam = Pinhole::make(s->camera.position, s->camera.target, s->camera.up, s->camera.fov, w, h);
+    size_t total = 0;
+    std::vector<RayRecord> rec;
+    for (uint32_t it = first_sample; it < first_sample + count; ++it) {
+        for (uint32_t y = 0; y < h; ++y) {
+            for (uint32_t x = 0; x < w; ++x) {
+                Sampler rng;
+                rng.mode = Sampler::COUNTER;
+                rng.key = ptx_path_key(seed, y * w + x, it);
+                Ray ray = sample_ray_for_pixel(cam, rng, x, y);
+                rec.clear();
+                trace_ray(sc, rng, ray, nullptr, &rec);
+                uint8_t bounce = 0;
+                for (const RayRecord& r : rec) {
+                    const bool shadow = r.t_hi == 1.0f;
+                    if (!shadow) ++bounce;
+                    Ray logged = r.ray;
+                    if (!shadow && r.hit) logged = Ray{r.ray.origin, r.hit->inner.t * r.ray.direction};  // Ray::extended
+                    if (total < cap) {
+                        uint8_t* b = out + 33 * total;
+                        const uint16_t i16 = (uint16_t)it, px = (uint16_t)x, py = (uint16_t)y;
+                        std::memcpy(b, &i16, 2);
+                        std::memcpy(b + 2, &px, 2);
+                        std::memcpy(b + 4, &py, 2);
+                        b[6] = bounce;
+                        b[7] = shadow ? 1 : 0;
+                        b[8] = r.hit ? 1 : 0;
+                        const float f[6] = {logged.origin.x, logged.origin.y, logged.origin.z,
+                                            logged.direction.x, logged.direction.y, logged.direction.z};
+                        std::memcpy(b + 9, f, 24);
+                    }
+                    ++total;
+                }
+            }
+        }
+    }
+    return total;
+}
+
 }  // extern "C"

@@ -39,6 +39,7 @@ def lib():
             getattr(L, name).restype = C.c_void_p
         L.orc_render.restype = C.c_double
         L.orc_bounce_rays.restype = C.c_size_t
+        L.orc_render_raylog.restype = C.c_size_t
         L.orc_wrap01.restype = C.c_float
         L.orc_wrap01.argtypes = [C.c_float]
         _lib = L
@@ -369,6 +370,13 @@ class Scene:
             keys = ["extend_rays", "shadow_rays", "extend_inner_nodes", "extend_tri_tests", "shadow_inner_nodes", "shadow_tri_tests", "extend_leaves", "shadow_leaves"]
             return accum, secs, dict(zip(keys, map(int, st)))
         return accum, secs
+
+    def render_raylog(self, w, h, seed=0, first_sample=0, count=1):
+        """Bytes of the raylog file one reference thread writes for these iterations (raylogger.rs:54-66)."""
+        n = lib().orc_render_raylog(self.h, w, h, C.c_uint64(seed), first_sample, count, None, C.c_size_t(0))
+        raw = np.zeros(n * 33, np.uint8)
+        lib().orc_render_raylog(self.h, w, h, C.c_uint64(seed), first_sample, count, _p(raw), C.c_size_t(n))
+        return raw
 
     def bounce_rays(self, w, h, bounces=10, seed=0, threads=8):
         fails = C.c_uint64()

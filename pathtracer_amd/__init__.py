@@ -143,6 +143,9 @@ def make_rays(origins, directions, tmin=0.0, tmax=FMAX):
     return r
 
 
+# tracing/src/raylogger.rs:54-66 (33 bytes, packed)
+RAYLOG_DTYPE = np.dtype([("iteration", "<u2"), ("px", "<u2"), ("py", "<u2"), ("bounces", "u1"), ("shadow", "u1"), ("intersect", "u1"),
+                         ("o", "<f4", 3), ("d", "<f4", 3)])
 FAIL_DTYPE = np.dtype([("i", "<u2"), ("o", "<f4", 3), ("d", "<f4", 3), ("correct", "<f4", 3), ("actual", "<f4", 3)])  # pybits/visualize_fails.py
 
 
@@ -306,6 +309,7 @@ class DeviceScene:
         _check(lib().ptx_scene_create(C.byref(desc), flags, C.byref(self._h)))
         self.max_bounces = desc.max_bounces
         self.n_lights = desc.n_lights
+        self._raylog_cap = 0
 
     @classmethod
     def from_arrays(cls, triangles, nodes, leaf_indices, normals=None, texcoords=None, material_ids=None,
@@ -433,6 +437,19 @@ class DeviceScene:
         n = C.c_uint32()
         _check(lib().ptx_check_fail_log(self._h, _ptr(raw), cap, C.byref(n)))
         return raw[: n.value * 50].view(FAIL_DTYPE)
+
+    def raylog_enable(self, max_records):
+        """The reference's `ray_logging` feature: log every ray of the following renders (0 = off)."""
+        _check(lib().ptx_raylog_enable(self._h, C.c_uint64(max_records)))
+        self._raylog_cap = int(max_records)
+
+    def raylog_read(self):
+        """(records in the reference's file order as RAYLOG_DTYPE, dropped count); empties the log."""
+        cap = self._raylog_cap
+        raw = np.zeros(cap * 33, np.uint8)
+        n, dropped = C.c_uint64(), C.c_uint64()
+        _check(lib().ptx_raylog_read(self._h, _ptr(raw), C.c_uint64(cap), C.byref(n), C.byref(dropped)))
+        return raw[: n.value * 33].view(RAYLOG_DTYPE), dropped.value
 
     def loop_profile(self):
         """Diagnostic (FLAG_COUNT_WORK scenes): lane occupancy of the traversal loop, per kernel."""

@@ -2,7 +2,9 @@
 // (pathtracer-cli/src/main.rs:53-85 flags, :87-121 progress line, :161-190 main), rendering through
 // libptx_mi355x.so.  `-t threads` x `-n iterations-per-thread` keeps its meaning as the total sample
 // count (there is no global spp flag in the reference, tracing/src/worker.rs:92); the GPU plays all threads.
-// Extra long flags (not in the reference): --seed N, --device D, --batch-samples S, --stats.
+// Extra long flags (not in the reference): --seed N, --device D, --batch-samples S, --stats, and
+// --ray-log FILE [--ray-log-max N]: what the reference writes to ./tmp/raylog0.bin when built with its
+// `ray_logging` feature (raylogger.rs), for all iterations, as one thread would.
 #include <hip/hip_runtime_api.h>
 
 #include <chrono>
@@ -26,6 +28,8 @@ struct Args {
     int device = 0;
     uint32_t batch_samples = 0;
     bool stats = false;
+    std::string ray_log;
+    uint64_t ray_log_max = 1ull << 26;  // records held on the device per iteration
 };
 
 [[noreturn]] void usage(const char* why) {
@@ -40,7 +44,8 @@ struct Args {
             "      --traverse-cost <F>                SAH kd-tree traverse cost [default: 1]\n"
             "      --intersect-cost <F>               SAH kd-tree intersect cost [default: 1.5]\n"
             "      --empty-factor <F>                 SAH kd-tree empty factor [default: 0.8]\n"
-            "      --seed <N> --device <D> --batch-samples <S> --stats   (MI355X extras)\n",
+            "      --seed <N> --device <D> --batch-samples <S> --stats   (MI355X extras)\n"
+            "      --ray-log <FILE> [--ray-log-max <RECORDS>]           33-byte ray records (raylogger.rs)\n",
             why);
     exit(2);
 }
@@ -101,6 +106,8 @@ int main(int argc, char** argv) {
         else if (k == "--device") a.device = atoi(val());
         else if (k == "--batch-samples") a.batch_samples = (uint32_t)strtoul(val(), nullptr, 10);
         else if (k == "--stats") a.stats = true;
+        else if (k == "--ray-log") a.ray_log = val();
+        else if (k == "--ray-log-max") a.ray_log_max = strtoull(val(), nullptr, 10);
         else usage(("unexpected argument '" + k + "'").c_str());
     }
     if (a.input.empty()) usage("the following required arguments were not provided: --input <INPUT>");
@@ -132,7 +139,28 @@ int main(int argc, char** argv) {
     std::vector<float> accum((size_t)a.width * a.height * 3, 0.0f);
     Progress prog{a.threads, total};
     auto t0 = std::chrono::steady_clock::now();
-    if (ptx_render(scene, &pinhole, a.seed, 0, total, accum.data(), on_progress, &prog)) die("render");
+    if (a.ray_log.empty()) {
+        if (ptx_render(scene, &pinhole, a.seed, 0, total, accum.data(), on_progress, &prog)) die("render");
+    } else {  // one iteration at a time, so that the log of one iteration is all the device has to hold
+        FILE* f = fopen(a.ray_log.c_str(), "wb");
+        if (!f) {
+            perror(a.ray_log.c_str());
+            return 1;
+        }
+        if (a.ray_log_max == 0 || ptx_raylog_enable(scene, a.ray_log_max)) die("ray log");
+        std::vector<uint8_t> bytes((size_t)a.ray_log_max * 33);
+        uint64_t dropped_total = 0;
+        for (uint32_t it = 0; it < total; ++it) {
+            if (ptx_render(scene, &pinhole, a.seed, it, 1, accum.data(), nullptr, nullptr)) die("render");
+            uint64_t n = 0, dropped = 0;
+            if (ptx_raylog_read(scene, bytes.data(), a.ray_log_max, &n, &dropped)) die("ray log");
+            fwrite(bytes.data(), 33, (size_t)n, f);
+            dropped_total += dropped;
+            on_progress(it + 1, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), &prog);
+        }
+        fclose(f);
+        if (dropped_total) fprintf(stderr, "\nray log: %llu records dropped (raise --ray-log-max)\n", (unsigned long long)dropped_total);
+    }
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     printf("\nTotal time: %.2fs\n", secs);
     if (a.stats) {

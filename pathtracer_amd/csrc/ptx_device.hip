@@ -15,6 +15,7 @@
 // Layout of this file: helpers, k_traverse, shading kernels, host-side state (ptx_scene), the entry points.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -69,6 +70,7 @@ struct RenderState {
     float4* sh_T;        // [i] {transport before this bounce's update, bits(pid)}
     float4* sh_contrib;  // [i * n_lights + l] {bsdf * emitted * |cos|, 0}
     uint8_t* sh_occ;     // [i * n_lights + l] 1 = occluded
+    uint8_t* sh_bounce;  // [i] bounce of the path that shot the shadow rays; only while the ray log is on, else null
     // Queues are SEGMENTED: segment s owns slots [s * seg_cap, (s + 1) * seg_cap) of every queue for the
     // whole batch; k_start fills the segments in path order, and workgroup s of k_shade / k_resolve reads
     // segment s and compacts its survivors to the front of segment s of the output queue with a counter of
@@ -737,6 +739,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, ui
             // bit for bit) and no separate contribution array is written
             if (NL == 1) st.sh_T[slot_s] = make_float4(T_old.x * sh_c[0].x, T_old.y * sh_c[0].y, T_old.z * sh_c[0].z, u2f(pid));
             else st.sh_T[slot_s] = make_float4(T_old.x, T_old.y, T_old.z, u2f(pid));
+            if (st.sh_bounce) st.sh_bounce[slot_s] = (uint8_t)bounce;
             for (uint32_t l = 0; l < (NL ? (uint32_t)NL : n_lights); ++l) {
                 const size_t j = (size_t)slot_s * n_lights + l;
                 reinterpret_cast<float4*>(st.sh_rays)[2 * j] = make_float4(point_above.x, point_above.y, point_above.z, 0.0f);
@@ -885,6 +888,74 @@ __global__ __launch_bounds__(BLOCK) void k_check(CheckArgs c) {
     }
 }
 
+// Ray log (tracing/src/raylogger.rs:39-66, filled from pathtracer.rs:34-43 and 69-71 when the reference is built
+// with its `ray_logging` feature): one record per extend ray - stretched to its hit point, `ray.extended(t)`,
+// when it hit - and per shadow ray.  Records are appended in queue order behind one counter (a wave reserves
+// its records with one atomic); `key` holds every integer field of the reference's record in the order the
+// reference writes them, so sorting by it on the host gives the reference's file order.
+struct LogRec {
+    unsigned long long key;  // iteration:16 | pixel_y:16 | pixel_x:16 | bounce:8 | shadow:1 | light:4 | intersect:1
+    float o[3], d[3];
+};
+struct LogArgs {
+    LogRec* recs;
+    unsigned long long* count;  // records produced so far (may pass cap: the excess is dropped)
+    unsigned long long cap;
+};
+
+template <bool SHADOW>
+__global__ __launch_bounds__(BLOCK) void k_log(RenderState st, LogArgs lg, uint32_t q, uint32_t n_lights) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t per = SHADOW ? n_lights : 1u;
+    for (uint32_t seg = blockIdx.x; seg < st.n_seg; seg += gridDim.x) {
+        const uint32_t count = (SHADOW ? st.seg_sh[seg] : st.seg_ext[q][seg]) * per;
+        for (uint32_t start = 0; start < count; start += BLOCK) {
+            const uint32_t k = start + threadIdx.x;
+            const bool active = k < count;
+            LogRec r{};
+            if (active) {
+                const uint32_t slot = seg * st.seg_cap + k / per, light = k % per;
+                uint32_t pid, bounce, intersect;
+                float4 ra, rb;
+                if (SHADOW) {
+                    const size_t j = (size_t)slot * n_lights + light;
+                    ra = reinterpret_cast<const float4*>(st.sh_rays)[2 * j];
+                    rb = reinterpret_cast<const float4*>(st.sh_rays)[2 * j + 1];
+                    pid = f2u(st.sh_T[slot].w);
+                    bounce = st.sh_bounce[slot];
+                    intersect = st.sh_occ[j];
+                } else {
+                    ra = reinterpret_cast<const float4*>(st.rays[q])[2 * (size_t)slot];
+                    rb = reinterpret_cast<const float4*>(st.rays[q])[2 * (size_t)slot + 1];
+                    pid = f2u(ra.w);
+                    bounce = f2u(rb.w);
+                    const uint4 h = reinterpret_cast<const uint4*>(st.hits)[slot];
+                    intersect = h.x != PTX_MISS ? 1u : 0u;
+                    if (intersect) {  // Ray::extended (geometry/src/ray.rs:21-26): t * direction
+                        const float t = u2f(h.y);
+                        rb.x = t * rb.x, rb.y = t * rb.y, rb.z = t * rb.z;
+                    }
+                }
+                const uint32_t pixel = image_pixel(st, pid % st.n_pixels), s = pid / st.n_pixels;
+                const unsigned long long it = (st.first_sample + s) & 0xFFFFu;
+                const unsigned long long px = (pixel % st.cam.width) & 0xFFFFu, py = (pixel / st.cam.width) & 0xFFFFu;
+                r.key = it << 46 | py << 30 | px << 14 | (unsigned long long)(bounce & 0xFFu) << 6 |
+                        (SHADOW ? 1ull : 0ull) << 5 | (unsigned long long)(light & 0xFu) << 1 | intersect;
+                r.o[0] = ra.x, r.o[1] = ra.y, r.o[2] = ra.z;
+                r.d[0] = rb.x, r.d[1] = rb.y, r.d[2] = rb.z;
+            }
+            const unsigned long long mask = __ballot(active);
+            if (mask) {
+                unsigned long long base = 0;
+                if (lane == (uint32_t)__ffsll((long long)mask) - 1u) base = atomicAdd(lg.count, (unsigned long long)__popcll(mask));
+                base = __shfl(base, __ffsll((long long)mask) - 1);
+                const unsigned long long at = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
+                if (active && at < lg.cap) lg.recs[at] = r;
+            }
+        }
+    }
+}
+
 // `*value += render_pixel(..)` (pathtracer.rs:138-140), samples added in index order.
 __global__ __launch_bounds__(BLOCK) void k_accumulate(RenderState st, float* __restrict__ accum) {
     for (uint32_t local = blockIdx.x * BLOCK + threadIdx.x; local < st.n_pixels; local += gridDim.x * BLOCK) {
@@ -995,7 +1066,7 @@ struct ptx_scene {
         DevBuf<ptx_hit> hits;
         DevBuf<float4> transq[2], radiance, sh_T, sh_contrib;
         DevBuf<ptx_ray> sh_rays;
-        DevBuf<uint8_t> sh_occ;
+        DevBuf<uint8_t> sh_occ, sh_bounce;
         DevBuf<uint2> spill;
         DevBuf<uint32_t> counts, segs;
         ~Pipe() {
@@ -1018,6 +1089,9 @@ struct ptx_scene {
     DevBuf<FailRec> fails;                   // PTX_FLAG_CHECK_BRUTE
     DevBuf<unsigned long long> check_count;  // [2] rays checked, fails found
     static constexpr uint32_t FAIL_CAP = 1u << 16;
+    DevBuf<LogRec> raylog;                    // ptx_raylog_enable
+    DevBuf<unsigned long long> raylog_count;  // [1] records produced
+    uint64_t raylog_cap = 0;                  // 0 = logging off
     uint64_t samples_done = 0;
     uint64_t batch_extend_rays = 0, batch_shadow_rays = 0;  // rays of the *_batch entry points
     uint64_t extend_launches = 0, shadow_launches = 0;
@@ -1129,6 +1203,7 @@ int ensure_render_state(ptx_scene* sc, size_t slots, size_t paths, uint32_t roun
         HIP_TRY(p.sh_rays.ensure(slots * L));
         if (L > 1) HIP_TRY(p.sh_contrib.ensure(slots * L));
         HIP_TRY(p.sh_occ.ensure(slots * L));
+        HIP_TRY(p.sh_bounce.ensure(slots));
         HIP_TRY(p.counts.ensure(6 * (size_t)rounds + 4));
         HIP_TRY(p.segs.ensure(4 * (size_t)sc->shade_grid));
     }
@@ -1576,6 +1651,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         st.sh_T = p.sh_T.p;
         st.sh_contrib = p.sh_contrib.p;
         st.sh_occ = p.sh_occ.p;
+        st.sh_bounce = sc->raylog_cap ? p.sh_bounce.p : nullptr;
         st.qcounts = p.counts.p;
         st.qmax = p.counts.p + (2 * rounds + 2);
         st.cursors = p.counts.p + (4 * rounds + 4);
@@ -1618,6 +1694,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
                                             p.spill.p, sc->totals.p + 2, stream);
                 if (rc) return rc;
                 if (sc->flags & PTX_FLAG_CHECK_BRUTE) launch_check(sc, st.rays[(b - 1) & 1], sr, st.hits, nullptr, stream);
+                if (sc->raylog_cap) k_log<false><<<(int)n_seg, BLOCK, 0, stream>>>(st, LogArgs{sc->raylog.p, sc->raylog_count.p, sc->raylog_cap}, (b - 1) & 1, 1u);
             }
             // k_shade(b) reuses the shadow queue and adds to the radiance: after resolve(b-1)
             if (overlap && b > 1) HIP_TRY(hipStreamWaitEvent(stream, p.ev_resolve, 0));
@@ -1647,6 +1724,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
                                                sc->totals.p + 4, sstream);
                     if (rc) return rc;
                     if (sc->flags & PTX_FLAG_CHECK_BRUTE) launch_check(sc, st.sh_rays, sr, nullptr, st.sh_occ, sstream);
+                    if (sc->raylog_cap) k_log<true><<<(int)n_seg, BLOCK, 0, sstream>>>(st, LogArgs{sc->raylog.p, sc->raylog_count.p, sc->raylog_cap}, 0u, L);
                 }
                 {
                     Timed tm(sc, sstream, KC_OTHER);
@@ -1806,6 +1884,52 @@ int ptx_check_fail_log(ptx_scene* sc, uint8_t* out, uint32_t cap_records, uint32
         memcpy(b + 2, f, 48);
     }
     *n_written = n;
+    return PTX_OK;
+}
+
+int ptx_raylog_enable(ptx_scene* sc, uint64_t max_records) {
+    int rc = check_scene(sc, "ptx_raylog_enable");
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (max_records) {
+        HIP_TRY(sc->raylog.ensure((size_t)max_records));
+        HIP_TRY(sc->raylog_count.ensure(1));
+        HIP_TRY(hipMemset(sc->raylog_count.p, 0, sizeof(unsigned long long)));
+    }
+    sc->raylog_cap = max_records;
+    return PTX_OK;
+}
+
+int ptx_raylog_read(ptx_scene* sc, uint8_t* out, uint64_t cap_records, uint64_t* n_written, uint64_t* n_dropped) {
+    int rc = check_scene(sc, "ptx_raylog_read");
+    if (rc) return rc;
+    if (!sc->raylog_cap) return fail(PTX_E_ARG, "ptx_raylog_read: the ray log is off (ptx_raylog_enable)");
+    if ((!out && cap_records) || !n_written) return fail(PTX_E_ARG, "ptx_raylog_read: null argument");
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long produced = 0;
+    HIP_TRY(hipMemcpy(&produced, sc->raylog_count.p, sizeof produced, hipMemcpyDeviceToHost));
+    const uint64_t kept = produced < sc->raylog_cap ? produced : sc->raylog_cap;
+    std::vector<LogRec> recs((size_t)kept);
+    if (kept) HIP_TRY(hipMemcpy(recs.data(), sc->raylog.p, (size_t)kept * sizeof(LogRec), hipMemcpyDeviceToHost));
+    // iteration, pixel row, pixel column, bounce, extend before shadow, light: the order the reference writes in
+    std::sort(recs.begin(), recs.end(), [](const LogRec& a, const LogRec& b) { return a.key < b.key; });
+    const uint64_t n = kept < cap_records ? kept : cap_records;
+    for (uint64_t i = 0; i < n; ++i) {  // RayLoggerWriter::write, raylogger.rs:54-66
+        const LogRec& r = recs[(size_t)i];
+        uint8_t* b = out + 33 * (size_t)i;
+        const uint16_t it = (uint16_t)(r.key >> 46), py = (uint16_t)(r.key >> 30), px = (uint16_t)(r.key >> 14);
+        memcpy(b, &it, 2);
+        memcpy(b + 2, &px, 2);
+        memcpy(b + 4, &py, 2);
+        b[6] = (uint8_t)(r.key >> 6);
+        b[7] = (uint8_t)((r.key >> 5) & 1u);
+        b[8] = (uint8_t)(r.key & 1u);
+        memcpy(b + 9, r.o, 12);
+        memcpy(b + 21, r.d, 12);
+    }
+    *n_written = n;
+    if (n_dropped) *n_dropped = produced - n;
+    HIP_TRY(hipMemset(sc->raylog_count.p, 0, sizeof(unsigned long long)));  // the log starts over
     return PTX_OK;
 }
 
