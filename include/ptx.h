@@ -208,6 +208,17 @@ int ptx_png_write_rgb8(const char* path, const uint8_t* rgb, uint32_t width, uin
 int ptx_png_read_linear(const char* path, float** rgb_out, uint32_t* width, uint32_t* height);
 void ptx_free(void* p);
 
+/* Accumulation-buffer checkpoint / resume (no counterpart in the reference, where an interrupted run loses its
+ * samples).  The file holds the image size, the seed, the number of samples already added and the
+ * f32 sums with a checksum.  Samples are keyed by (seed, pixel, sample index) and reach a pixel in index order,
+ * so ptx_render(first_sample = samples) on top of a loaded buffer ends with the bits of one uninterrupted run.
+ * ptx_accum_load with accum_rgb == NULL only reads the header into width/height/seed/samples; with a buffer,
+ * width and height are inputs that the file must match. */
+int ptx_accum_save(const char* path, const float* accum_rgb, uint32_t width, uint32_t height, uint64_t seed,
+                   uint32_t samples);
+int ptx_accum_load(const char* path, float* accum_rgb, uint32_t* width, uint32_t* height, uint64_t* seed,
+                   uint32_t* samples);
+
 /* ---- device side: the hot path ----------------------------------------------------------------- */
 
 /* Upload a scene to the current HIP device. */

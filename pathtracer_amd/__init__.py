@@ -474,6 +474,22 @@ def write_png(path, rgb8):
     _check(lib().ptx_png_write_rgb8(os.fsencode(path), _ptr(a), a.shape[1], a.shape[0]))
 
 
+def save_accum(path, accum, seed, samples):
+    """Accumulation-buffer checkpoint: H x W x 3 float32 sums + seed + samples done (ptx_accum_save)."""
+    a = np.ascontiguousarray(accum, np.float32)
+    assert a.ndim == 3 and a.shape[2] == 3
+    _check(lib().ptx_accum_save(os.fsencode(path), _ptr(a), a.shape[1], a.shape[0], C.c_uint64(seed), samples))
+
+
+def load_accum(path):
+    """(accum H x W x 3, seed, samples done) of a checkpoint; continue with render(first_sample=samples)."""
+    w, h, seed, n = C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_uint32()
+    _check(lib().ptx_accum_load(os.fsencode(path), None, C.byref(w), C.byref(h), C.byref(seed), C.byref(n)))
+    a = np.zeros((h.value, w.value, 3), np.float32)
+    _check(lib().ptx_accum_load(os.fsencode(path), _ptr(a), C.byref(w), C.byref(h), C.byref(seed), C.byref(n)))
+    return a, seed.value, n.value
+
+
 def read_png_linear(path):
     p = C.POINTER(C.c_float)()
     w, h = C.c_uint32(), C.c_uint32()

@@ -2,7 +2,8 @@
 // (pathtracer-cli/src/main.rs:53-85 flags, :87-121 progress line, :161-190 main), rendering through
 // libptx_mi355x.so.  `-t threads` x `-n iterations-per-thread` keeps its meaning as the total sample
 // count (there is no global spp flag in the reference, tracing/src/worker.rs:92); the GPU plays all threads.
-// Extra long flags (not in the reference): --seed N, --device D, --batch-samples S, --stats, and
+// Extra long flags (not in the reference): --seed N, --device D, --batch-samples S, --stats, --checkpoint FILE / --resume FILE
+// (accumulation buffer save / continue), and
 // --ray-log FILE [--ray-log-max N]: what the reference writes to ./tmp/raylog0.bin when built with its
 // `ray_logging` feature (raylogger.rs), for all iterations, as one thread would.
 #include <hip/hip_runtime_api.h>
@@ -28,7 +29,7 @@ struct Args {
     int device = 0;
     uint32_t batch_samples = 0;
     bool stats = false;
-    std::string ray_log;
+    std::string ray_log, checkpoint, resume;
     uint64_t ray_log_max = 1ull << 26;  // records held on the device per iteration
 };
 
@@ -45,7 +46,9 @@ struct Args {
             "      --intersect-cost <F>               SAH kd-tree intersect cost [default: 1.5]\n"
             "      --empty-factor <F>                 SAH kd-tree empty factor [default: 0.8]\n"
             "      --seed <N> --device <D> --batch-samples <S> --stats   (MI355X extras)\n"
-            "      --ray-log <FILE> [--ray-log-max <RECORDS>]           33-byte ray records (raylogger.rs)\n",
+            "      --ray-log <FILE> [--ray-log-max <RECORDS>]           33-byte ray records (raylogger.rs)\n"
+            "      --checkpoint <FILE>                save the accumulation buffer after the render\n"
+            "      --resume <FILE>                    continue a saved buffer (its seed; iterations are added)\n",
             why);
     exit(2);
 }
@@ -107,6 +110,8 @@ int main(int argc, char** argv) {
         else if (k == "--batch-samples") a.batch_samples = (uint32_t)strtoul(val(), nullptr, 10);
         else if (k == "--stats") a.stats = true;
         else if (k == "--ray-log") a.ray_log = val();
+        else if (k == "--checkpoint") a.checkpoint = val();
+        else if (k == "--resume") a.resume = val();
         else if (k == "--ray-log-max") a.ray_log_max = strtoull(val(), nullptr, 10);
         else usage(("unexpected argument '" + k + "'").c_str());
     }
@@ -137,10 +142,16 @@ int main(int argc, char** argv) {
     const uint32_t total = a.threads * a.iterations_per_thread;
     printf("Rendering %ux%u px image with %u thread(s) and %u total iteration(s)...\n", a.width, a.height, a.threads, total);
     std::vector<float> accum((size_t)a.width * a.height * 3, 0.0f);
+    uint32_t first = 0;  // samples already in the buffer
+    if (!a.resume.empty()) {
+        uint32_t w = a.width, h = a.height;
+        if (ptx_accum_load(a.resume.c_str(), accum.data(), &w, &h, &a.seed, &first)) die("resume");
+        printf("Resuming %s: %u iteration(s) done, seed %llu\n", a.resume.c_str(), first, (unsigned long long)a.seed);
+    }
     Progress prog{a.threads, total};
     auto t0 = std::chrono::steady_clock::now();
     if (a.ray_log.empty()) {
-        if (ptx_render(scene, &pinhole, a.seed, 0, total, accum.data(), on_progress, &prog)) die("render");
+        if (ptx_render(scene, &pinhole, a.seed, first, total, accum.data(), on_progress, &prog)) die("render");
     } else {  // one iteration at a time, so that the log of one iteration is all the device has to hold
         FILE* f = fopen(a.ray_log.c_str(), "wb");
         if (!f) {
@@ -151,7 +162,7 @@ int main(int argc, char** argv) {
         std::vector<uint8_t> bytes((size_t)a.ray_log_max * 33);
         uint64_t dropped_total = 0;
         for (uint32_t it = 0; it < total; ++it) {
-            if (ptx_render(scene, &pinhole, a.seed, it, 1, accum.data(), nullptr, nullptr)) die("render");
+            if (ptx_render(scene, &pinhole, a.seed, first + it, 1, accum.data(), nullptr, nullptr)) die("render");
             uint64_t n = 0, dropped = 0;
             if (ptx_raylog_read(scene, bytes.data(), a.ray_log_max, &n, &dropped)) die("ray log");
             fwrite(bytes.data(), 33, (size_t)n, f);
@@ -172,9 +183,11 @@ int main(int argc, char** argv) {
                c.extend_ms > 0 ? c.extend_rays / c.extend_ms / 1e3 : 0.0, (unsigned long long)c.shadow_rays, c.shadow_ms,
                c.shadow_ms > 0 ? c.shadow_rays / c.shadow_ms / 1e3 : 0.0, c.shade_ms, c.generate_ms);
     }
+    if (!a.checkpoint.empty() && ptx_accum_save(a.checkpoint.c_str(), accum.data(), a.width, a.height, a.seed, first + total))
+        die("checkpoint");
     printf("Writing %s...\n", a.output.c_str());
     std::vector<uint8_t> rgb(accum.size());
-    ptx_tonemap_rgb8(accum.data(), a.width, a.height, total, rgb.data());
+    ptx_tonemap_rgb8(accum.data(), a.width, a.height, first + total, rgb.data());
     if (ptx_png_write_rgb8(a.output.c_str(), rgb.data(), a.width, a.height)) die("write");
     ptx_scene_destroy(scene);
     ptx_loaded_free(loaded);

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -198,6 +199,83 @@ int ptx_png_read_linear(const char* path, float** rgb_out, uint32_t* width, uint
     *rgb_out = out;
     *width = w;
     *height = h;
+    return PTX_OK;
+}
+
+// Accumulation-buffer checkpoint (the reference has none: a run that stops loses its samples).
+// Little-endian file: "PTXACC01", width u32, height u32, seed u64, samples u32, crc32 of the pixel bytes u32,
+// then width * height * 3 f32 sums.  Samples are keyed by (seed, pixel, sample index) and added in index
+// order, so rendering [samples, N) on top of a loaded buffer gives the bits of one uninterrupted run.
+int ptx_accum_save(const char* path, const float* accum_rgb, uint32_t width, uint32_t height, uint64_t seed,
+                   uint32_t samples) {
+    if (!path || !accum_rgb || !width || !height) return fail(PTX_E_ARG, "ptx_accum_save: bad argument");
+    const size_t bytes = (size_t)width * height * 3 * sizeof(float);
+    uLong crc = crc32(0, nullptr, 0);
+    for (size_t off = 0; off < bytes; off += (size_t)1 << 30) {
+        const size_t n = bytes - off < ((size_t)1 << 30) ? bytes - off : (size_t)1 << 30;
+        crc = crc32(crc, reinterpret_cast<const Bytef*>(accum_rgb) + off, (uInt)n);
+    }
+    const std::string tmp = std::string(path) + ".tmp";  // written aside and renamed: never a torn checkpoint
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return fail(PTX_E_IO, std::string("ptx_accum_save: cannot create ") + tmp);
+    uint8_t head[32];
+    memcpy(head, "PTXACC01", 8);
+    memcpy(head + 8, &width, 4);
+    memcpy(head + 12, &height, 4);
+    memcpy(head + 16, &seed, 8);
+    memcpy(head + 24, &samples, 4);
+    const uint32_t c32 = (uint32_t)crc;
+    memcpy(head + 28, &c32, 4);
+    bool ok = fwrite(head, 1, sizeof head, f) == sizeof head && fwrite(accum_rgb, 1, bytes, f) == bytes;
+    ok = fclose(f) == 0 && ok;
+    if (!ok || rename(tmp.c_str(), path) != 0) {
+        remove(tmp.c_str());
+        return fail(PTX_E_IO, std::string("ptx_accum_save: cannot write ") + path);
+    }
+    return PTX_OK;
+}
+
+// accum_rgb == NULL only reads the header (to size the buffer); otherwise the buffer must hold
+// *width x *height as passed in, and the file must match them.
+int ptx_accum_load(const char* path, float* accum_rgb, uint32_t* width, uint32_t* height, uint64_t* seed,
+                   uint32_t* samples) {
+    if (!path || !width || !height) return fail(PTX_E_ARG, "ptx_accum_load: bad argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(PTX_E_IO, std::string("ptx_accum_load: cannot open ") + path);
+    uint8_t head[32];
+    if (fread(head, 1, sizeof head, f) != sizeof head || memcmp(head, "PTXACC01", 8) != 0) {
+        fclose(f);
+        return fail(PTX_E_IO, std::string("ptx_accum_load: not an accumulation checkpoint: ") + path);
+    }
+    uint32_t w, h, n, c32;
+    uint64_t sd;
+    memcpy(&w, head + 8, 4);
+    memcpy(&h, head + 12, 4);
+    memcpy(&sd, head + 16, 8);
+    memcpy(&n, head + 24, 4);
+    memcpy(&c32, head + 28, 4);
+    if (seed) *seed = sd;
+    if (samples) *samples = n;
+    if (!accum_rgb) {
+        *width = w, *height = h;
+        fclose(f);
+        return PTX_OK;
+    }
+    if (w != *width || h != *height) {
+        fclose(f);
+        return fail(PTX_E_ARG, "ptx_accum_load: the checkpoint is " + std::to_string(w) + "x" + std::to_string(h) +
+                                   ", the buffer " + std::to_string(*width) + "x" + std::to_string(*height));
+    }
+    const size_t bytes = (size_t)w * h * 3 * sizeof(float);
+    const bool ok = fread(accum_rgb, 1, bytes, f) == bytes && fgetc(f) == EOF;
+    fclose(f);
+    if (!ok) return fail(PTX_E_IO, std::string("ptx_accum_load: truncated or oversized checkpoint: ") + path);
+    uLong crc = crc32(0, nullptr, 0);
+    for (size_t off = 0; off < bytes; off += (size_t)1 << 30) {
+        const size_t k = bytes - off < ((size_t)1 << 30) ? bytes - off : (size_t)1 << 30;
+        crc = crc32(crc, reinterpret_cast<const Bytef*>(accum_rgb) + off, (uInt)k);
+    }
+    if ((uint32_t)crc != c32) return fail(PTX_E_IO, std::string("ptx_accum_load: checksum mismatch in ") + path);
     return PTX_OK;
 }
 

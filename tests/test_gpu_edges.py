@@ -180,3 +180,34 @@ def test_tiles_add_up_to_the_full_frame():
         with pytest.raises(pt.PtxError):
             dev.render_region_device(ph, *bad, 1, one.data_ptr(), stream=stream)
     dev.close()
+
+
+def test_checkpoint_resume_equals_uninterrupted_run(tmp_path):
+    """[0, 3) saved, loaded, continued with [3, 7) == [0, 7) in one go, bit for bit; same through the CLI."""
+    import subprocess
+
+    scene = pt.LoadedScene(os.path.join(SCENES, "cornell.obj"), max_bounces=6)
+    dev = scene.upload()
+    ph = scene.pinhole(48, 40)
+    whole = dev.render(ph, 7, seed=21)
+    part = dev.render(ph, 3, seed=21)
+    ck = str(tmp_path / "run.ptxacc")
+    pt.save_accum(ck, part, seed=21, samples=3)
+    acc, seed, done = pt.load_accum(ck)
+    assert (seed, done) == (21, 3)
+    dev.render(ph, 7 - done, seed=seed, first_sample=done, accum=acc)
+    assert acc.tobytes() == whole.tobytes()
+    dev.close()
+
+    exe = os.path.join(ROOT, "pathtracer_amd", "bin", "pathtracer-cli")
+    common = [exe, "-i", os.path.join(SCENES, "cornell.obj"), "-s", "48x40", "-m", "6", "-t", "1"]
+    a, b, c = (str(tmp_path / n) for n in ("a.png", "b.png", "c.png"))
+    ck2 = str(tmp_path / "cli.ptxacc")
+    for args in (["-o", a, "-n", "7", "--seed", "21"], ["-o", b, "-n", "3", "--seed", "21", "--checkpoint", ck2],
+                 ["-o", c, "-n", "4", "--resume", ck2, "--checkpoint", ck2]):
+        r = subprocess.run(common + args, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+    assert "Resuming" in r.stdout and "3 iteration(s) done" in r.stdout
+    assert open(a, "rb").read() == open(c, "rb").read()
+    acc2, seed2, done2 = pt.load_accum(ck2)
+    assert (seed2, done2) == (21, 7) and acc2.tobytes() == whole.tobytes()

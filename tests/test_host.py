@@ -208,3 +208,38 @@ def test_serial_and_parallel_builds_are_the_same_tree():
     digests = {subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PTX_BUILD_THREADS=t), capture_output=True, text=True,
                               check=True).stdout.strip() for t in ("1", "2", "16")}
     assert len(digests) == 1 and len(digests.pop()) == 64
+
+
+def test_accum_checkpoint_round_trip_and_damage(tmp_path):
+    """ptx_accum_save / ptx_accum_load: bits, header, and the ways a file can be wrong."""
+    rng = np.random.default_rng(3)
+    acc = rng.random((13, 17, 3), dtype=np.float32) * 40
+    acc[0, 0] = [0.0, np.float32(1e-40), np.float32(3e38)]
+    path = str(tmp_path / "a.ptxacc")
+    pt.save_accum(path, acc, seed=2**63 + 5, samples=77)
+    got, seed, n = pt.load_accum(path)
+    assert got.tobytes() == acc.tobytes() and seed == 2**63 + 5 and n == 77
+    assert os.path.getsize(path) == 32 + acc.nbytes and not os.path.exists(path + ".tmp")
+    raw = bytearray(open(path, "rb").read())
+    for damage in ("flip", "short", "long", "magic"):
+        bad = bytearray(raw)
+        if damage == "flip":
+            bad[100] ^= 1
+        elif damage == "short":
+            bad = bad[:-4]
+        elif damage == "long":
+            bad += b"\0"
+        else:
+            bad[0] = ord("X")
+        open(path, "wb").write(bad)
+        with pytest.raises(pt.PtxError):
+            pt.load_accum(path)
+    with pytest.raises(pt.PtxError):
+        pt.load_accum(str(tmp_path / "missing"))
+    # a buffer of another size is refused
+    open(path, "wb").write(raw)
+    import ctypes as C
+
+    w, h = C.c_uint32(16), C.c_uint32(13)
+    buf = np.zeros((13, 16, 3), np.float32)
+    assert pt.lib().ptx_accum_load(os.fsencode(path), buf.ctypes.data_as(C.c_void_p), C.byref(w), C.byref(h), None, None) == -1  # PTX_E_ARG
