@@ -4,9 +4,10 @@
 A step = one pass of the wavefront path tracer (generate → [extend → shade → shadow] x max_bounces →
 accumulate) over one batch of `--spp-per-step` samples of every pixel of the workload; inputs (scene,
 accumulation buffer) are resident in HBM before the timed region.  Default workload = BASELINE.json
-configs[2]: cornell_teapot.obj, 1080x1080, 4 steps x 256 spp = 1024 spp per GPU, max_bounces 10 (one step = one
-batch of 256 samples of every pixel = 299 M paths in flight, ~69 GB of queues; larger batches amortise the
-long-ray tail of every launch: 128 / 256 spp per batch = 1.26 / 1.35 G samples/s).
+configs[2]: cornell_teapot.obj, 1080x1080, 4 steps x 640 spp = 2560 spp per GPU, max_bounces 10 (one step = one
+batch of 640 samples of every pixel = 747 M paths in flight, ~133 GB of queues out of the 288 GB; wider batches
+amortise the long-ray tail of every launch and the small late bounces: 128 / 256 / 640 spp per batch =
+1.26 / 1.44 / 1.55 G samples/s; the library sizes its batches from the free device memory).
 
 Multi-GPU: one process per GPU (torchrun), the scene replicated, every rank renders its own sample
 range (global sample index = rank * steps * spp + ...; counter-based sampler, so ranks never overlap),
@@ -40,7 +41,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scene", default="cornell_teapot")
     ap.add_argument("--size", default="1080x1080")
-    ap.add_argument("--spp-per-step", type=int, default=256)
+    ap.add_argument("--spp-per-step", type=int, default=640)
     ap.add_argument("--max-bounces", type=int, default=10)
     ap.add_argument("--batch-samples", type=int, default=0, help="samples in flight per launch batch (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -1046,7 +1046,8 @@ struct ptx_scene {
 
     // render state (allocated on first render, grown on demand)
     uint32_t batch_samples = 0;  // 0 = choose from the image size
-    uint64_t slot_budget = 0;    // queue slots over all pipelines, 0 = default (PTX_SLOTS_MI environment variable: Mi slots)
+    uint64_t slot_budget = 0;    // queue slots over all pipelines (ptx_set_queue_slots, PTX_SLOTS_MI = Mi slots); 0 = from auto_bytes
+    uint64_t auto_bytes = 0;     // 60 % of the device memory that was free when the scene was created
     size_t cap_slots = 0, cap_paths = 0;
     uint32_t cap_rounds = 0, last_rounds = 0;
     // One pipeline = the queues and state of one sample batch in flight on its own stream.  Batches are
@@ -1166,18 +1167,9 @@ void resolve_stamps(ptx_scene* sc) {
     sc->stamps.clear();
 }
 
-// slots = queue entries per pipeline (n_seg x seg_cap), paths = path ids per batch (radiance),
-// rounds = extend/shade/shadow rounds per batch (bookkeeping words)
-int ensure_render_state(ptx_scene* sc, size_t slots, size_t paths, uint32_t rounds) {
+int grow_render_state(ptx_scene* sc, size_t slots, size_t paths, uint32_t rounds) {
     const uint32_t L = sc->dev.n_lights ? sc->dev.n_lights : 1u;
-    if (sc->pipes.size() == sc->n_pipes && slots <= sc->cap_slots && paths <= sc->cap_paths && rounds <= sc->cap_rounds)
-        return PTX_OK;
-    HIP_TRY(hipDeviceSynchronize());
     if (!sc->ev_fork) HIP_TRY(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
-    // every pipeline, old or new, holds the high-water marks
-    if (slots < sc->cap_slots) slots = sc->cap_slots;
-    if (paths < sc->cap_paths) paths = sc->cap_paths;
-    if (rounds < sc->cap_rounds) rounds = sc->cap_rounds;
     sc->pipes.resize(sc->n_pipes);
     sc->last_pipe = 0;
     for (auto& up : sc->pipes) {
@@ -1193,6 +1185,8 @@ int ensure_render_state(ptx_scene* sc, size_t slots, size_t paths, uint32_t roun
             HIP_TRY(up->spill2.ensure((size_t)(PTX_MAX_DEPTH - LDS_DEPTH) * sc->tgrid * TBLOCK));
         }
         ptx_scene::Pipe& p = *up;
+        // per slot: 2 x 32 rays + 2 x 16 transport + 16 hit + 16 shadow record + 1 bounce, and per light
+        // 32 shadow ray + 1 occlusion flag (+ 16 contribution when there are several lights)
         for (int q = 0; q < 2; ++q) {
             HIP_TRY(p.rays[q].ensure(slots));
             HIP_TRY(p.transq[q].ensure(slots));
@@ -1210,6 +1204,27 @@ int ensure_render_state(ptx_scene* sc, size_t slots, size_t paths, uint32_t roun
     if (!sc->totals.p) {
         HIP_TRY(sc->totals.ensure(32));
         HIP_TRY(hipMemset(sc->totals.p, 0, 32 * sizeof(unsigned long long)));
+    }
+    return PTX_OK;
+}
+
+// slots = queue entries per pipeline (n_seg x seg_cap), paths = path ids per batch (radiance),
+// rounds = extend/shade/shadow rounds per batch (bookkeeping words).  On failure every pipeline is released
+// (the caller may try again with less).
+int ensure_render_state(ptx_scene* sc, size_t slots, size_t paths, uint32_t rounds) {
+    if (sc->pipes.size() == sc->n_pipes && slots <= sc->cap_slots && paths <= sc->cap_paths && rounds <= sc->cap_rounds)
+        return PTX_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    // every pipeline, old or new, holds the high-water marks
+    if (slots < sc->cap_slots) slots = sc->cap_slots;
+    if (paths < sc->cap_paths) paths = sc->cap_paths;
+    if (rounds < sc->cap_rounds) rounds = sc->cap_rounds;
+    const int rc = grow_render_state(sc, slots, paths, rounds);
+    if (rc != PTX_OK) {
+        sc->pipes.clear();
+        sc->cap_slots = sc->cap_paths = 0;
+        sc->cap_rounds = 0;
+        return rc;
     }
     sc->cap_slots = slots;
     sc->cap_paths = paths;
@@ -1409,10 +1424,15 @@ int ptx_scene_create(const ptx_scene_desc* d, uint32_t flags, ptx_scene** out) {
     }
     sc->tgrid = prop.multiProcessorCount * PTX_BLOCKS_PER_CU;  // sized so that the LDS of a CU is filled
     sc->flags = flags;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)64 << 30;
+        sc->auto_bytes = (uint64_t)(free_b * 0.6);
+    }
     if (const char* e = getenv("PTX_OVERLAP")) sc->overlap_shadow = atoi(e) != 0;
     if (const char* e = getenv("PTX_SLOTS_MI")) {
         const long v = atol(e);
-        if (v >= 1 && v <= 511) sc->slot_budget = (uint64_t)v << 20;
+        if (v >= 1 && v <= 4000) sc->slot_budget = (uint64_t)v << 20;  // clamped by the index limit at render time
     }
     if (const char* e = getenv("PTX_PIPES")) {
         int k = atoi(e);
@@ -1552,7 +1572,7 @@ int ptx_set_batch_samples(ptx_scene* sc, uint32_t samples_per_batch) {
 
 int ptx_set_queue_slots(ptx_scene* sc, uint64_t slots) {
     if (!sc) return fail(PTX_E_ARG, "ptx_set_queue_slots: null scene");
-    if (slots >= (1ull << 29)) return fail(PTX_E_LIMIT, "ptx_set_queue_slots: at most 2^29 - 1 slots");
+    if (slots >= (1ull << 32)) return fail(PTX_E_LIMIT, "ptx_set_queue_slots: at most 2^32 - 1 slots");
     sc->slot_budget = slots;
     return PTX_OK;
 }
@@ -1586,47 +1606,61 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
     // Batches.  The last rays of a launch finish ~0.3 ms after its cursor drains, and the late bounces of a
     // batch are small launches that cannot fill the chip (measured at 1080^2: 64 / 128 / 256 / 448 samples per
     // batch = 1.0 / 1.26 / 1.35 / 1.45 G samples/s), so a batch should be as long as possible.  Two budgets
-    // bound it: queue SLOTS (~215 B each; default 320 Mi = ~67 GB of the 288 GB) and path ids (16 B of
-    // radiance each, < 2^29).  A batch with more paths than slots runs with path regeneration:
+    // bound it: queue SLOTS (~180 B each; default 320 Mi = ~57 GB of the 288 GB; slot x light indices are 32-bit)
+    // and path ids (16 B of radiance each, < 2^31).  A batch with more paths than slots runs with path regeneration:
     // every queue segment starts the next paths of its range as earlier ones end (see RenderState), so all
     // launches but the last few stay slot-wide.
     const uint32_t n_pipes = sc->n_pipes;
     const uint32_t B = sc->dev.max_bounces, L = sc->dev.n_lights;
-    const uint64_t slot_budget = (sc->slot_budget ? sc->slot_budget : (320ull << 20)) / n_pipes;
-    const uint64_t max_batch_paths = (1ull << 29) - (1ull << 20);
-    uint32_t S = sc->batch_samples;  // samples per batch
-    if (S == 0) {
-        // up to 8 slot-loads of paths per batch (bounds the number of rounds), spread evenly over the pipelines
-        const uint64_t by_rounds = 8 * slot_budget / n_pixels, by_ids = max_batch_paths / n_pixels;
-        uint64_t most = by_rounds < by_ids ? by_rounds : by_ids;
-        if (most < 1) most = 1;
-        const uint32_t per_pipe = (sample_count + n_pipes - 1) / n_pipes;
-        S = (uint32_t)(most < per_pipe ? most : (per_pipe ? per_pipe : 1));
+    // bytes per queue slot (see ensure_render_state) + the radiance of up to two paths per slot
+    const uint64_t slot_bytes = 129 + (uint64_t)(L ? L : 1u) * (33 + (L > 1 ? 16 : 0)) + 32;
+    uint64_t slot_budget = (sc->slot_budget ? sc->slot_budget : sc->auto_bytes / slot_bytes) / n_pipes;
+    const uint64_t max_batch_paths = (1ull << 31) - (1ull << 20);
+    uint32_t S = 1, n_seg = 1, seg_range = 1, seg_cap = 64, rounds = 0;
+    uint32_t want_S = sc->batch_samples;  // samples per batch, 0 = choose
+    for (int attempt = 0;; ++attempt) {
+        const uint64_t index_limit = ((1ull << 32) - (1ull << 22)) / (L ? L : 1u);  // shadow-ray indices = slot * L + l
+        if (slot_budget > index_limit) slot_budget = index_limit;
+        S = want_S;
+        if (S == 0) {
+            // up to 2 slot-loads of paths per batch, spread evenly over the pipelines
+            const uint64_t by_rounds = 2 * slot_budget / n_pixels, by_ids = max_batch_paths / n_pixels;
+            uint64_t most = by_rounds < by_ids ? by_rounds : by_ids;
+            if (most < 1) most = 1;
+            const uint32_t per_pipe = (sample_count + n_pipes - 1) / n_pipes;
+            S = (uint32_t)(most < per_pipe ? most : (per_pipe ? per_pipe : 1));
+        }
+        while ((uint64_t)S * n_pixels > max_batch_paths && S > 1) S = (S + 1) / 2;
+        if (S < 1) S = 1;
+        if (sample_count > 0) {  // equal-sized batches, their number a multiple of the pipeline count when possible
+            uint32_t n_batches = (sample_count + S - 1) / S;
+            if (want_S == 0 && n_batches > 1) n_batches = (n_batches + n_pipes - 1) / n_pipes * n_pipes;
+            if (n_batches > sample_count) n_batches = sample_count;
+            S = (sample_count + n_batches - 1) / n_batches;
+        }
+        // queue segments (see RenderState): one per k_shade workgroup; seg_range paths each, seg_cap of them live
+        const uint64_t batch_paths = (uint64_t)S * n_pixels;
+        n_seg = (uint32_t)sc->shade_grid;
+        if ((batch_paths + 255) / 256 < n_seg) n_seg = (uint32_t)((batch_paths + 255) / 256);
+        if (n_seg < 1) n_seg = 1;
+        seg_range = (uint32_t)((batch_paths + n_seg - 1) / n_seg);
+        seg_cap = (uint32_t)((seg_range + 63) / 64 * 64);
+        {
+            const uint64_t by_budget = slot_budget / n_seg / 64 * 64;
+            if (by_budget >= 64 && by_budget < seg_cap) seg_cap = (uint32_t)by_budget;
+        }
+        // a slot turns over after at most B rounds: B x ceil(range / cap) rounds start and finish every path
+        rounds = B * ((seg_range + seg_cap - 1) / seg_cap);
+        const int rc = ensure_render_state(sc, (size_t)n_seg * seg_cap, (size_t)batch_paths, rounds);
+        if (rc == PTX_OK) break;
+        // out of device memory (somebody else holds it): everything was released; try again half as wide
+        if (rc != PTX_E_OOM || attempt >= 6 || (uint64_t)n_seg * seg_cap <= (1u << 16)) return rc;
+        (void)hipGetLastError();
+        slot_budget = (uint64_t)n_seg * seg_cap / 2;
+        if (want_S > 1) want_S = (S + 1) / 2;
     }
-    while ((uint64_t)S * n_pixels > max_batch_paths && S > 1) S = (S + 1) / 2;
-    if (S < 1) S = 1;
-    if (sample_count > 0) {  // equal-sized batches, their number a multiple of the pipeline count when possible
-        uint32_t n_batches = (sample_count + S - 1) / S;
-        if (sc->batch_samples == 0 && n_batches > 1) n_batches = (n_batches + n_pipes - 1) / n_pipes * n_pipes;
-        if (n_batches > sample_count) n_batches = sample_count;
-        S = (sample_count + n_batches - 1) / n_batches;
-    }
-    // queue segments (see RenderState): one per k_shade workgroup; seg_range paths each, seg_cap of them live
-    const uint64_t batch_paths = (uint64_t)S * n_pixels;
-    uint32_t n_seg = (uint32_t)sc->shade_grid;
-    if ((batch_paths + 255) / 256 < n_seg) n_seg = (uint32_t)((batch_paths + 255) / 256);
-    if (n_seg < 1) n_seg = 1;
-    const uint32_t seg_range = (uint32_t)((batch_paths + n_seg - 1) / n_seg);
-    uint32_t seg_cap = (uint32_t)((seg_range + 63) / 64 * 64);
-    {
-        const uint64_t by_budget = slot_budget / n_seg / 64 * 64;
-        if (by_budget >= 64 && by_budget < seg_cap) seg_cap = (uint32_t)by_budget;
-    }
-    // a slot turns over after at most B rounds: B x ceil(range / cap) rounds start and finish every path
-    const uint32_t rounds = B * ((seg_range + seg_cap - 1) / seg_cap);
-    int rc = ensure_render_state(sc, (size_t)n_seg * seg_cap, (size_t)batch_paths, rounds);
-    if (rc) return rc;
     sc->last_rounds = rounds;
+    int rc = PTX_OK;
 
     const int grid = sc->grid;
     auto t0 = std::chrono::steady_clock::now();

@@ -140,7 +140,7 @@ def test_argument_errors():
     with pytest.raises(pt.PtxError):
         dev.set_pipelines(9)
     with pytest.raises(pt.PtxError):
-        dev.set_queue_slots(1 << 29)
+        dev.set_queue_slots(1 << 32)
     ph = scene.pinhole(16, 16)
     assert not dev.render(ph, 0).any()  # zero samples: nothing added
     with pytest.raises(pt.PtxError):
@@ -211,3 +211,27 @@ def test_checkpoint_resume_equals_uninterrupted_run(tmp_path):
     assert open(a, "rb").read() == open(c, "rb").read()
     acc2, seed2, done2 = pt.load_accum(ck2)
     assert (seed2, done2) == (21, 7) and acc2.tobytes() == whole.tobytes()
+
+
+def test_render_shrinks_its_queues_when_device_memory_is_short():
+    """The queue budget comes from the memory that is free at scene creation; when an allocation fails later
+    (somebody else took the memory) the batch is retried half as wide until it fits - same image, bit for bit."""
+    import torch
+
+    scene = pt.LoadedScene(os.path.join(SCENES, "cornell.obj"), max_bounces=5)
+    dev = scene.upload()
+    ph = scene.pinhole(1024, 1024)
+    want = dev.render(ph, 48, seed=3)  # 50 M paths in one batch: ~9 GB of queues
+    dev.close()
+    dev = scene.upload()
+    free_b, _ = torch.cuda.mem_get_info()
+    hog = torch.empty(free_b - (4 << 30), dtype=torch.uint8, device="cuda")  # leaves ~4 GB
+    try:
+        got = dev.render(ph, 48, seed=3)
+        ext, _ = dev.last_batch_counts()
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    assert got.tobytes() == want.tobytes()
+    assert len(ext) > 5  # narrower queues: path regeneration ran more rounds than bounces
+    dev.close()
