@@ -283,11 +283,18 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
     __syncthreads();
     // Windows: `chunk` rays of one segment, ~4 per wave over the launch (64..512).  Every segment gets as many
     // windows as the fullest one needs (segment-major, so neighbouring waves work on neighbouring rays); the
-    // ones past the end of a shorter segment are skipped.
-    const unsigned long long est = (unsigned long long)max_count * n_seg / (gridDim.x * (TBLOCK / 64) * 4u);
+    // ones past the end of a shorter segment are skipped.  The last `tail` rays of every segment (about two
+    // rounds of 64 rays per wave over the launch) are handed out in windows of 64 after all the large ones, so
+    // that the launch does not end with a few waves working through a large window each.
+    const uint32_t n_waves = gridDim.x * (TBLOCK / 64);
+    const unsigned long long est = (unsigned long long)max_count * n_seg / (n_waves * 4u);
     const uint32_t chunk = est >= 512u ? 512u : (est >= 256u ? 256u : (est >= 128u ? 128u : 64u));
-    const uint32_t wps = (max_count + chunk - 1u) / chunk;  // windows per segment
-    const uint32_t n_windows = wps * n_seg;
+    const uint32_t tail = chunk > 64u ? ((2u * n_waves + n_seg - 1u) / n_seg) * 64u : 0u;  // per segment
+    const uint32_t head_max = max_count > tail ? max_count - tail : 0u;
+    const uint32_t wps_a = (head_max + chunk - 1u) / chunk;        // large windows per segment
+    const uint32_t wps_b = chunk > 64u ? tail / 64u : 0u;          // 64-ray windows per segment
+    const uint32_t n_a = wps_a * n_seg;
+    const uint32_t n_windows = n_a + wps_b * n_seg;
     uint32_t lo = 0, hi = 0;
     bool drained = false;  // the launch's cursor has passed the last window
     int32_t cur = DESC_IDLE;
@@ -324,12 +331,17 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                     drained = true;
                     break;
                 }
-                const uint32_t seg = w / wps, k = w - seg * wps;
+                const bool large = w < n_a;
+                const uint32_t wl = large ? w : w - n_a, per = large ? wps_a : wps_b;
+                const uint32_t seg = wl / per, k = wl - seg * per;
                 const uint32_t cnt = segmented ? a.seg_counts[seg] * a.count_scale : a.fixed_count;
-                const uint32_t first = k * chunk;
-                if (first >= cnt) continue;  // this segment is shorter than the fullest one
+                const uint32_t head = cnt > tail ? cnt - tail : 0u;  // rays of this segment handed out in large windows
+                const uint32_t first = large ? k * chunk : head + k * 64u;
+                const uint32_t end = large ? head : cnt;
+                if (first >= end) continue;  // this segment is shorter than the fullest one
+                const uint32_t len = large ? chunk : 64u;
                 lo = seg * seg_stride + first;
-                hi = seg * seg_stride + (first + chunk < cnt ? first + chunk : cnt);
+                hi = seg * seg_stride + (first + len < end ? first + len : end);
             }
             const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
             const uint32_t n_idle = (uint32_t)__popcll(idle);
