@@ -299,7 +299,8 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
     bool drained = false;  // the launch's cursor has passed the last window
     int32_t cur = DESC_IDLE;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, t_end = 0, t1 = 0, t2 = 0;
-    uint32_t ridx = 0;
+    constexpr uint32_t NO_RAY = 0xFFFFFFFFu;
+    uint32_t ridx = NO_RAY;  // ray whose answer this lane holds or works on
     uint32_t so = so0 + LVL;  // offset of the next free stack slot; so0 + LVL == empty
     uint32_t bi = PTX_MISS;
     float bt = 0.0f, bu = 0.0f, bv = 0.0f;  // stay 0 while bi == PTX_MISS
@@ -318,6 +319,18 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
 
     for (;;) {
         if (COUNT) pf_refill += lane == 0 ? 1u : 0u;
+        // ---- write out the answers of the lanes that have finished since the last refill: once per refill
+        // with many lanes, instead of inside the stepping loop whenever a single lane finishes
+        if (cur == DESC_IDLE && ridx != NO_RAY) {
+            if (ANY) {
+                // (resolving here - radiance[path] += contribution for an unoccluded ray - was measured slower
+                // than the separate streaming k_resolve: the scattered read-modify-write stalls the whole wave)
+                a.occ[ridx] = bi != PTX_MISS ? 1 : 0;
+            } else {
+                reinterpret_cast<uint4*>(a.hits)[ridx] = make_uint4(bi, f2u(bt), f2u(bu), f2u(bv));
+            }
+            ridx = NO_RAY;
+        }
         // ---- refill idle lanes from the wave's window
         for (;;) {
             const unsigned long long idle = __ballot(cur == DESC_IDLE);
@@ -444,17 +457,8 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                     top = PTX_SPILL(st);
                     if (sb > so_last) tb = PTX_SPILL(sb).y;
                 }
+                // a finished lane keeps its answer in registers until the next refill writes it out (see above)
                 const bool done = bi != PTX_MISS || t2 == t_end || st == so0;
-                if (done) {
-                    if (ANY) {
-                        // (resolving here - radiance[path] += contribution for an unoccluded ray - was
-                        // measured slower than the separate streaming k_resolve: the scattered
-                        // read-modify-write stalls the whole wave)
-                        a.occ[ridx] = bi != PTX_MISS ? 1 : 0;
-                    } else {
-                        reinterpret_cast<uint4*>(a.hits)[ridx] = make_uint4(bi, f2u(bt), f2u(bu), f2u(bv));
-                    }
-                }
                 cur = done ? DESC_IDLE : (int32_t)top.x;
                 t1 = done ? t1 : u2f(top.y);
                 t2 = done ? t2 : u2f(tb);
