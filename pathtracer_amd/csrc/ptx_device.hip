@@ -61,11 +61,15 @@ struct DevScene {
     uint32_t max_bounces;
 };
 
+struct Rad {  // packed rgb: one dwordx3 per access
+    float x, y, z;
+};
+
 struct RenderState {
     ptx_ray* rays[2];
     ptx_hit* hits;
     float4* transq[2];  // accumulated transport of the entries of extend queue A / B (travels with the ray)
-    float4* radiance;
+    Rad* radiance;       // [path id] accumulated radiance of the sample (12 bytes)
     ptx_ray* sh_rays;    // [i * n_lights + l] shadow ray: origin point_above, direction target - origin, t in [0,1]
     float4* sh_T;        // [i] {transport before this bounce's update, bits(pid)}
     float4* sh_contrib;  // [i * n_lights + l] {bsdf * emitted * |cos|, 0}
@@ -511,7 +515,7 @@ __device__ inline void start_path(const RenderState& st, ptx_ray* __restrict__ r
     reinterpret_cast<float4*>(rays)[2 * (size_t)slot] = make_float4(st.cam.position[0], st.cam.position[1], st.cam.position[2], u2f(pid));
     reinterpret_cast<float4*>(rays)[2 * (size_t)slot + 1] = make_float4(dx, dy, dz, u2f(1u));
     trans[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-    st.radiance[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    st.radiance[pid] = Rad{0.0f, 0.0f, 0.0f};
 }
 
 // Tops segment `seg` of `rays` (holding `have` entries) up with the next unstarted paths of its range.
@@ -676,7 +680,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, ui
             const V3 T = v3(Traw.x, Traw.y, Traw.z);
             if (hraw.x == PTX_MISS) {
                 // return accumulated_radiance + accumulated_transport * environment (pathtracer.rs:44-46)
-                float4 R = st.radiance[pid];
+                Rad R = st.radiance[pid];
                 R.x = R.x + T.x * sc.env[0];
                 R.y = R.y + T.y * sc.env[1];
                 R.z = R.z + T.z * sc.env[2];
@@ -790,7 +794,7 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(RenderState st, uint32_t boun
         const uint32_t pid = f2u(T.w);
         if (n_lights == 1u) {  // k_shade<1> stored transport * contribution
             if (!st.sh_occ[i]) {
-                float4 R = st.radiance[pid];
+                Rad R = st.radiance[pid];
                 R.x = R.x + T.x;
                 R.y = R.y + T.y;
                 R.z = R.z + T.z;
@@ -808,7 +812,7 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(RenderState st, uint32_t boun
             }
             incoming = incoming + c;
         }
-        float4 R = st.radiance[pid];
+        Rad R = st.radiance[pid];
         R.x = R.x + T.x * incoming.x;
         R.y = R.y + T.y * incoming.y;
         R.z = R.z + T.z * incoming.z;
@@ -978,7 +982,7 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(RenderState st, float* __r
         const uint32_t pixel = image_pixel(st, local);
         float r = accum[3 * (size_t)pixel], g = accum[3 * (size_t)pixel + 1], b = accum[3 * (size_t)pixel + 2];
         for (uint32_t s = 0; s < st.n_samples; ++s) {
-            const float4 v = st.radiance[(size_t)s * st.n_pixels + local];
+            const Rad v = st.radiance[(size_t)s * st.n_pixels + local];
             r += v.x;
             g += v.y;
             b += v.z;
@@ -1081,7 +1085,8 @@ struct ptx_scene {
         hipEvent_t ev_accum = nullptr, ev_join = nullptr;
         DevBuf<ptx_ray> rays[2];
         DevBuf<ptx_hit> hits;
-        DevBuf<float4> transq[2], radiance, sh_T, sh_contrib;
+        DevBuf<float4> transq[2], sh_T, sh_contrib;
+        DevBuf<Rad> radiance;
         DevBuf<ptx_ray> sh_rays;
         DevBuf<uint8_t> sh_occ, sh_bounce;
         DevBuf<uint2> spill;
@@ -1623,13 +1628,13 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
     // batch are small launches that cannot fill the chip (measured at 1080^2: 64 / 128 / 256 / 448 samples per
     // batch = 1.0 / 1.26 / 1.35 / 1.45 G samples/s), so a batch should be as long as possible.  Two budgets
     // bound it: queue SLOTS (~180 B each; default 320 Mi = ~57 GB of the 288 GB; slot x light indices are 32-bit)
-    // and path ids (16 B of radiance each, < 2^31).  A batch with more paths than slots runs with path regeneration:
+    // and path ids (12 B of radiance each, < 2^31).  A batch with more paths than slots runs with path regeneration:
     // every queue segment starts the next paths of its range as earlier ones end (see RenderState), so all
     // launches but the last few stay slot-wide.
     const uint32_t n_pipes = sc->n_pipes;
     const uint32_t B = sc->dev.max_bounces, L = sc->dev.n_lights;
     // bytes per queue slot (see ensure_render_state) + the radiance of up to two paths per slot
-    const uint64_t slot_bytes = 129 + (uint64_t)(L ? L : 1u) * (33 + (L > 1 ? 16 : 0)) + 32;
+    const uint64_t slot_bytes = 129 + (uint64_t)(L ? L : 1u) * (33 + (L > 1 ? 16 : 0)) + 24;
     uint64_t slot_budget = (sc->slot_budget ? sc->slot_budget : sc->auto_bytes / slot_bytes) / n_pipes;
     const uint64_t max_batch_paths = (1ull << 31) - (1ull << 20);
     uint32_t S = 1, n_seg = 1, seg_range = 1, seg_cap = 64, rounds = 0;
@@ -1722,7 +1727,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         st.first_sample = first_sample + done;
         HIP_TRY(hipMemsetAsync(p.counts.p, 0, (6 * (size_t)rounds + 4) * sizeof(uint32_t), stream));
         if (rounds == 0) {  // max_bounces == 0: nothing is traced (the reference's loop body never runs)
-            HIP_TRY(hipMemsetAsync(p.radiance.p, 0, (size_t)st.n_paths * sizeof(float4), stream));
+            HIP_TRY(hipMemsetAsync(p.radiance.p, 0, (size_t)st.n_paths * sizeof(Rad), stream));
         } else {
             Timed tm(sc, stream, KC_GENERATE);
             k_start<<<(int)n_seg, BLOCK, 0, stream>>>(st);
