@@ -186,9 +186,10 @@ __device__ inline void wave_add(unsigned long long* dst, uint32_t v) {
 //       x = bits of the plane distance, y = axis, z = descriptor of the LEFT child, w = of the RIGHT child
 //   a descriptor (int32) says what a child is without visiting it:
 //       >= 0              index of an inner node
-//       0x80000000 | off  leaf with two or more triangles: dev_leaf[off ..] holds their indices, bit 31
-//                         set on the last one
-//       0xC0000000 | idx  leaf with exactly one triangle (the index is inline)
+//       0x80000000 | off  leaf: leaf_tris[off ..] holds COPIES of its triangle records in leaf order, each
+//                         with the triangle's index and a "last of the leaf" flag in its spare word, so a
+//                         leaf visit is one dependent fetch (record) instead of two (index, then record)
+//                         and the records of a leaf share cache lines
 //       DESC_EXIT  (-1)   empty leaf, which is the same thing as "this lane must leave its leaf"
 //       DESC_IDLE  (-2)   the lane holds no ray
 //   so a lane's whole control state is ONE register (`cur`), every predicate of the loop is one compare,
@@ -199,8 +200,8 @@ __device__ inline void wave_add(unsigned long long* dst, uint32_t v) {
 //   * every wave owns a cursor window [lo,hi) of the ray array, taken `chunk` rays at a time with ONE
 //     atomic on the launch's cursor; lanes whose ray has finished are refilled from the window as soon
 //     as REFILL_IDLE lanes of the wave are idle, so a long ray never holds 63 idle lanes hostage;
-//   * each loop iteration steps all node-walking lanes by one node; the triangle step (one index load,
-//     three 16-byte loads) only runs when at least TRI_BATCH lanes are waiting for it or no lane can
+//   * each loop iteration steps all node-walking lanes by one node; the triangle step (three
+//     16-byte loads of one record) only runs when at least TRI_BATCH lanes are waiting for it or no lane can
 //     walk any further; lanes that have left their leaf pop or finish in the same iteration;
 //   * the traversal stack (far child descriptor, t_split) lives in LDS for the first LDS_DEPTH levels
 //     ([level][thread]: ds_write_b64 / ds_read_b64 without bank conflicts) and in a per-thread global
@@ -235,16 +236,15 @@ constexpr uint32_t TRI_BATCH_NEAREST = PTX_TRI_BATCH;  // lanes that must wait i
 constexpr uint32_t TRI_BATCH_ANYHIT = PTX_TRI_BATCH_ANY;
 
 constexpr int32_t DESC_EXIT = -1, DESC_IDLE = -2;
-constexpr uint32_t DESC_MULTI = 0x80000000u, DESC_SINGLE = 0xC0000000u, DESC_PAYLOAD = 0x3FFFFFFFu;
-constexpr uint32_t DESC_MAX_PAYLOAD = 0x3FFFFFFDu;  // keeps DESC_SINGLE | idx clear of the two specials
+constexpr uint32_t DESC_LEAF = 0x80000000u, DESC_PAYLOAD = 0x3FFFFFFFu;
+constexpr uint32_t DESC_MAX_PAYLOAD = 0x3FFFFFFDu;  // offsets and triangle indices stay below 2^30 - 2
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct TravArgs {
     const uint4* nodes;        // inner nodes, device layout
     uint32_t top_n;            // nodes [0, top_n) are copied into LDS by every workgroup (<= TOP_NODES)
-    const uint32_t* leaf_list; // triangle indices of the multi-triangle leaves, last one flagged
-    const TriRec* tris;
+    const TriRec* tris;        // leaf_tris: records in leaf order, f[10] = triangle index | last << 31
     const ptx_ray* rays;
     // rays [0, fixed_count), or (seg_counts != NULL) the first seg_counts[s] * count_scale rays of every
     // segment s, segments seg_cap * count_scale rays apart; *max_ptr = the largest seg_counts[s]
@@ -424,18 +424,17 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                 if (COUNT) pf_tri_iter += lane == 0 ? 1u : 0u;
                 if (cur < -2) {  // one triangle of the leaf: geometry/src/geometry.rs:176-196
                     if (COUNT) ++pf_tri, ++n_tris;
-                    uint32_t e = (uint32_t)cur;
-                    if (e < DESC_SINGLE) e = a.leaf_list[e & DESC_PAYLOAD];
-                    const uint32_t idx = e & DESC_PAYLOAD;
-                    const bool last = (int32_t)e < 0;
                     TriRec rec;  // the whole 48-byte record in one go; the kind is its last word
                     {
-                        const float4* rp = reinterpret_cast<const float4*>(a.tris + idx);
+                        const float4* rp = reinterpret_cast<const float4*>(a.tris + ((uint32_t)cur & DESC_PAYLOAD));
                         const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
                         __builtin_memcpy(&rec.f[0], &r0, 16);
                         __builtin_memcpy(&rec.f[4], &r1, 16);
                         __builtin_memcpy(&rec.f[8], &r2, 16);
                     }
+                    const uint32_t tag = f2u(rec.f[10]);
+                    const uint32_t idx = tag & DESC_PAYLOAD;
+                    const bool last = (int32_t)tag < 0;
                     float t, u, v;
                     bool accept = false;
                     if (tri_test(rec, ox, oy, oz, dx, dy, dz, t, u, v) && t1 <= t && t <= t2) {
@@ -1051,7 +1050,7 @@ struct ptx_scene {
     bool shading = false;
     DevBuf<ptx_kdnode> nodes;
     DevBuf<uint4> dev_nodes;     // traversal layout (see k_traverse)
-    DevBuf<uint32_t> dev_leaf;  // triangle lists of the multi-triangle leaves, last entry flagged
+    DevBuf<TriRec> leaf_tris;   // triangle records in leaf order, index + last flag in f[10] (see k_traverse)
     int32_t root_desc = DESC_EXIT;
     uint32_t top_n = 0;  // inner nodes served from LDS
     int tgrid = 1024;  // traversal workgroups (TBLOCK threads each)
@@ -1270,10 +1269,6 @@ std::string build_device_tree(const ptx_kdnode* in, uint32_t n_nodes, const uint
     auto leaf_desc = [&](uint32_t src) -> uint32_t {
         const uint32_t cnt = in[src].w1 >> 2, off = in[src].w0;
         if (cnt == 0) return (uint32_t)DESC_EXIT;
-        if (cnt == 1) {
-            if (leaf_idx[off] > DESC_MAX_PAYLOAD) too_big = true;
-            return DESC_SINGLE | (leaf_idx[off] & DESC_PAYLOAD);
-        }
         const size_t at = list.size();
         if (at + cnt > DESC_MAX_PAYLOAD) {
             too_big = true;
@@ -1284,7 +1279,7 @@ std::string build_device_tree(const ptx_kdnode* in, uint32_t n_nodes, const uint
             list.push_back(leaf_idx[off + k] & DESC_PAYLOAD);
         }
         list.back() |= 0x80000000u;
-        return DESC_MULTI | (uint32_t)at;
+        return DESC_LEAF | (uint32_t)at;
     };
     nodes.clear();
     list.clear();
@@ -1345,10 +1340,9 @@ int launch_traverse(ptx_scene* sc, const ptx_ray* d_rays, const SegRange& sr, ui
     const bool count = (sc->flags & PTX_FLAG_COUNT_WORK) != 0 && work;
     TravArgs a{};
     a.nodes = sc->dev_nodes.p;
-    a.leaf_list = sc->dev_leaf.p;
     a.top_n = sc->top_n;
     a.root = sc->root_desc;
-    a.tris = sc->dev.tris;
+    a.tris = sc->leaf_tris.p;
     a.rays = d_rays;
     a.seg_counts = sr.counts;
     a.max_ptr = sr.max_ptr;
@@ -1472,7 +1466,12 @@ int ptx_scene_create(const ptx_scene_desc* d, uint32_t flags, ptx_scene** out) {
         const std::string big = build_device_tree(d->nodes, d->n_nodes, d->leaf_indices, dn, dl, sc->root_desc, sc->top_n);
         if (!big.empty()) return fail(PTX_E_LIMIT, "ptx_scene_create: " + big);
         HIP_TRY(sc->dev_nodes.upload(dn.data(), dn.size()));
-        HIP_TRY(sc->dev_leaf.upload(dl.data(), dl.size()));
+        std::vector<TriRec> lt(dl.size());  // the records in leaf order, tagged with index and last flag
+        for (size_t k = 0; k < dl.size(); ++k) {
+            lt[k] = recs[dl[k] & DESC_PAYLOAD];
+            lt[k].f[10] = u2f(dl[k]);
+        }
+        HIP_TRY(sc->leaf_tris.upload(lt.data(), lt.size()));
     }
     HIP_TRY(sc->leaf_idx.upload(d->leaf_indices, d->n_leaf_indices));
     HIP_TRY(sc->tris.upload(recs.data(), recs.size()));
