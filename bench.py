@@ -29,9 +29,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # HBM bytes per extend ray of the default workload from the PMC passes of this round
-# (profiles/r01_v12_pmc_fetch_write.txt: k_traverse<nearest>, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 over the
+# (profiles/r01_v13_pmc_fetch_write.txt: k_traverse<nearest>, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 over the
 # rays of the profiled run; FETCH_SIZE doubled as MI355X_MICROARCH.md "HBM" prescribes for gfx950).
-MEASURED_EXTEND_HBM_BYTES_PER_RAY = {"cornell_teapot": 98.7}
+MEASURED_EXTEND_HBM_BYTES_PER_RAY = {"cornell_teapot": 152.0}
 
 
 def main():
