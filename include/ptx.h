@@ -260,13 +260,14 @@ int ptx_set_batch_samples(ptx_scene* scene, uint32_t samples_per_batch);
 int ptx_render_region_device(ptx_scene* scene, const ptx_pinhole* camera, uint32_t x, uint32_t y, uint32_t width,
                              uint32_t height, uint64_t seed, uint32_t first_sample, uint32_t sample_count,
                              float* d_accum, void* stream);
-/* Queue slots (paths in flight) over all pipelines; 0 = default (320 Mi, ~67 GB).  A batch with more paths
+/* Queue slots (paths in flight) over all pipelines; 0 = default: what fits in 60 % of the device memory that
+ * was free when the scene was created (162 bytes per slot with one light).  A batch with more paths
  * than slots is rendered with path regeneration: finished paths are replaced by the next camera rays of the
  * batch, so the memory stays bounded while every launch stays wide.  Results do not depend on it. */
 int ptx_set_queue_slots(ptx_scene* scene, uint64_t slots);
-/* Sample batches rendered concurrently, each on a HIP stream of its own (1..8, default 2 or the
- * PTX_PIPES environment variable).  With 1 every kernel has the GPU to itself, which is what a
- * per-kernel measurement wants; results do not depend on it.  No counterpart in the reference. */
+/* Sample batches rendered concurrently, each on a HIP stream of its own (1..8, default 1 or the
+ * PTX_PIPES environment variable).  With 1 every kernel has the GPU to itself (one wide batch was measured
+ * faster than two narrower overlapped ones); results do not depend on it.  No counterpart in the reference. */
 int ptx_set_pipelines(ptx_scene* scene, uint32_t pipelines);
 
 /* Queue lengths of the most recent render batch: extend_counts[r] / shadow_counts[r] = entries of round r+1

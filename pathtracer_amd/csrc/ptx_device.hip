@@ -1625,8 +1625,9 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
     const uint32_t n_pixels = (uint32_t)n_pixels64;
     // Batches.  The last rays of a launch finish ~0.3 ms after its cursor drains, and the late bounces of a
     // batch are small launches that cannot fill the chip (measured at 1080^2: 64 / 128 / 256 / 448 samples per
-    // batch = 1.0 / 1.26 / 1.35 / 1.45 G samples/s), so a batch should be as long as possible.  Two budgets
-    // bound it: queue SLOTS (~180 B each; default 320 Mi = ~57 GB of the 288 GB; slot x light indices are 32-bit)
+    // batch = 1.0 / 1.26 / 1.35 / 1.45 G samples/s), so a batch should be as wide as possible.  Two budgets
+    // bound it: queue SLOTS (162 B each with one light; default: 60 % of the memory that was free when the scene
+    // was created; slot x light indices are 32-bit)
     // and path ids (12 B of radiance each, < 2^31).  A batch with more paths than slots runs with path regeneration:
     // every queue segment starts the next paths of its range as earlier ones end (see RenderState), so all
     // launches but the last few stay slot-wide.
