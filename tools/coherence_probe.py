@@ -38,6 +38,9 @@ for bn in (0, 1, 2):
     # octant within blocks of 64 Ki rays (what a per-segment binning could do)
     blk = np.arange(len(r)) // 65536
     run("bounce %d by octant within 64Ki" % (bn + 1), r[np.lexsort((octant, blk))])
+    for chunk in (256, 1024, 4096):  # what a bucketing inside one k_shade workgroup pass could do
+        blk = np.arange(len(r)) // chunk
+        run("bounce %d by octant within %d" % (bn + 1, chunk), r[np.lexsort((octant, blk))])
     ax = np.abs(dd).argmax(1) * 2 + (dd[np.arange(len(dd)), np.abs(dd).argmax(1)] < 0)
     run("bounce %d by major axis (6 bins)" % (bn + 1), r[np.argsort(ax, kind="stable")])
     run("bounce %d random" % (bn + 1), r[np.random.default_rng(0).permutation(len(r))])
