@@ -7,7 +7,8 @@ this image, so these vectors come from the restatement, not from th
 
 Per scene: 2048 bounced rays (kdtree-tester-cli methodology) + 2048 synthetic rays with their
 (index,t,u,v) from the POINTER-tree traversal, the flat-tree digest and statistics, and a 24x24, 2-spp
-radiance image in counter-sampler mode (seed 2024)."""
+radiance image in counter-sampler mode (seed 2024).  raylog.npz: the 33-byte ray records (raylogger.rs:54-66) of
+a 16x12 render, iterations 1 and 2, max_bounces 6, seed 2024, for cornell (one light) and sr2 (four)."""
 import hashlib
 import os
 import sys
@@ -61,5 +62,17 @@ def main():
         print(name, len(rays), "rays", st, digest[:12])
 
 
+def raylogs():
+    out = {}
+    for name in ("cornell", "sr2"):
+        sc = orc.Scene(os.path.join(ROOT, "scenes", name + ".obj"), max_bounces=6)
+        out[name] = sc.render_raylog(16, 12, seed=2024, first_sample=1, count=2)
+        print(name, len(out[name]) // 33, "ray records")
+    np.savez_compressed(os.path.join(HERE, "raylog.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "raylog":
+        raylogs()
+        sys.exit(0)
     main()

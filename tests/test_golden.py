@@ -54,3 +54,29 @@ def test_gpu_reproduces_golden(name):
     img = dev.render(scene.pinhole(24, 24), 2, seed=2024)
     assert img.tobytes() == g["image"].tobytes()
     dev.close()
+
+
+RAYLOG = dict(w=16, h=12, seed=2024, first_sample=1, count=2, max_bounces=6)
+
+
+@pytest.mark.parametrize("name", ["cornell", "sr2"])
+def test_oracle_reproduces_golden_raylog(name):
+    want = np.load(os.path.join(GOLD, "raylog.npz"))[name]
+    sc = orc.Scene(os.path.join(ROOT, "scenes", name + ".obj"), max_bounces=RAYLOG["max_bounces"])
+    got = sc.render_raylog(RAYLOG["w"], RAYLOG["h"], seed=RAYLOG["seed"], first_sample=RAYLOG["first_sample"], count=RAYLOG["count"])
+    assert got.tobytes() == want.tobytes()
+    recs = want.view(pt.RAYLOG_DTYPE)
+    assert len(recs) > 400 and set(np.unique(recs["iteration"])) == {1, 2} and recs["px"].max() == 15 and recs["py"].max() == 11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cornell", "sr2"])
+def test_gpu_reproduces_golden_raylog(name):
+    want = np.load(os.path.join(GOLD, "raylog.npz"))[name]
+    scene = pt.LoadedScene(os.path.join(ROOT, "scenes", name + ".obj"), max_bounces=RAYLOG["max_bounces"])
+    dev = scene.upload()
+    dev.raylog_enable(len(want) // 33 + 1)
+    dev.render(scene.pinhole(RAYLOG["w"], RAYLOG["h"]), RAYLOG["count"], seed=RAYLOG["seed"], first_sample=RAYLOG["first_sample"])
+    got, dropped = dev.raylog_read()
+    assert dropped == 0 and got.tobytes() == want.tobytes()
+    dev.close()
