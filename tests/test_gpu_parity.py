@@ -80,6 +80,26 @@ def test_reference_kdtree_vectors_on_gpu():  # kdtree/src/lib.rs:202-467
     dev.close()
 
 
+def test_reference_embedded_sr2_ray_on_gpu():  # kdtree-tester-cli/src/reducer.rs:104-117
+    """k_traverse (nearest and any-hit) on the one real-scene vector the reference holds: sr2, index 7589."""
+    import torch
+
+    from test_oracle_kat import SR2_RAY, SR2_REFERENCE
+
+    dev = pt.LoadedScene(os.path.join(SCENES, "sr2.obj")).upload()
+    rays = np.concatenate([pt.make_rays([SR2_RAY[0]], [SR2_RAY[1]], 0.0, tmax) for tmax in (1.0, pt.FMAX)] * 40)  # > one wave
+    hits = dev.intersect(rays)
+    want = (SR2_REFERENCE[0],) + tuple(map(f32, SR2_REFERENCE[1:]))
+    for h in hits:
+        assert (int(h["index"]), f32(h["t"]), f32(h["u"]), f32(h["v"])) == want
+    d_rays = torch.from_numpy(rays.view(np.uint8).copy()).cuda()
+    d_out = torch.zeros(len(rays), dtype=torch.uint8, device="cuda")
+    dev.occluded_device(d_rays.data_ptr(), len(rays), d_out.data_ptr())
+    torch.cuda.synchronize()
+    assert d_out.cpu().numpy().all()
+    dev.close()
+
+
 @pytest.mark.parametrize("name,res", [("cornell", 96), ("cornell_teapot", 96), ("cornell_textured", 64), ("sr2", 64), ("cubesplosion", 64)])
 def test_extend_bit_exact_vs_oracle(name, res):
     """Config 2: kdtree-tester-cli bounced ray set + synthetic rays; GPU == CPU pointer-tree traversal."""

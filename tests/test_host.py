@@ -123,6 +123,17 @@ def test_host_traversal_reference_vectors():  # kdtree/src/lib.rs:202-467 throug
     assert got == (0, f32(0.5687325), f32(0.66772085), f32(0.24024889))
 
 
+def test_reference_embedded_sr2_ray_through_the_product_host_path():  # kdtree-tester-cli/src/reducer.rs:104-117
+    """Product loader (OBJ face order), product SAH builder and the product's scalar traversal give the
+    reference's brute-force answer for the one real-scene ray the reference embeds."""
+    from test_oracle_kat import SR2_RAY, SR2_REFERENCE
+
+    tree = pt.LoadedScene(os.path.join(SCENES, "sr2.obj")).kdtree()
+    for tmax in (1.0, pt.FMAX):
+        h = tree.intersect_host(SR2_RAY[0], SR2_RAY[1], (0.0, tmax))
+        assert (int(h["index"]), f32(h["t"]), f32(h["u"]), f32(h["v"])) == (SR2_REFERENCE[0],) + tuple(map(f32, SR2_REFERENCE[1:]))
+
+
 def test_host_traversal_matches_oracle_on_random_rays():
     scene = pt.LoadedScene(os.path.join(SCENES, "cornell.obj"))
     tree = scene.kdtree()

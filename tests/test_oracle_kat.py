@@ -522,3 +522,33 @@ def test_to_rgb8():
     expect = lambda p: int(np.round(min((p / 2.0) ** (1 / 2.2), 1.0) * 255))
     assert list(out[0]) == [0, expect(1.0), 255]
     assert list(out[1][:2]) == [expect(0.5), 255]
+
+
+# ---------------------------------------------------------------- kdtree-tester-cli/src/reducer.rs:104-117
+# The one real-scene vector the reference holds: a shadow ray on sr2.obj (towards the light at (-10, 10, 10),
+# t in [0, 1] as ray_bouncer.rs:84-95 shoots it) with the brute-force ("reference") answer 7589 and the answer
+# 5556 of a kd-tree bug of the past.  Both records are Möller–Trumbore results on real triangles, so they pin
+# the OBJ face order -> triangle index mapping and the (t, u, v) arithmetic against the reference itself.
+SR2_RAY = ([3.897963, 0.24242611, -4.203691], [-13.897963, 9.757574, 14.2036915])
+SR2_REFERENCE = (7589, 0.0004729527, 0.09395919, 0.47453666)
+SR2_PAST_BUG = (5556, 0.05429069, 0.2189177, 0.74337834)
+
+
+def sr2_path():
+    import os
+
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes", "sr2.obj")
+
+
+def test_reference_embedded_sr2_ray():
+    scene = orc.Scene(sr2_path())
+    tris = scene.export()["triangles"].reshape(-1, 3, 3)
+    ray = (np.array(SR2_RAY[0], f32), np.array(SR2_RAY[1], f32))
+    for index, t, u, v in (SR2_REFERENCE, SR2_PAST_BUG):  # each triangle on its own, both intersection routes
+        assert orc.triangle_intersect(tris[index], ray) == (f32(t), f32(u), f32(v))
+        assert orc.triangle_intersect(tris[index], ray, as_any=True) == (f32(t), f32(u), f32(v))
+    tree = scene.tree()
+    for tmax in (1.0, FMAX):  # the tester's shadow range and the extend range
+        rays = orc.make_rays([SR2_RAY[0]], [SR2_RAY[1]], 0.0, tmax)
+        for hit in (tree.brute(rays)[0], tree.intersect(rays)[0]):  # brute force, then the kd-tree: the bug is gone
+            assert (int(hit["index"]), f32(hit["t"]), f32(hit["u"]), f32(hit["v"])) == (SR2_REFERENCE[0],) + tuple(map(f32, SR2_REFERENCE[1:]))
