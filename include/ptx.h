@@ -8,9 +8,11 @@
  *  - every call returns int: 0 = ok, <0 = error class (PTX_E_*); ptx_last_error() gives the text
  *    (thread-local).  No exception crosses the boundary.
  *  - handles are opaque; the library copies what it needs and never keeps a caller pointer after return.
- *  - one handle = one GPU (the current HIP device at create time).  Calls on one handle are not
- *    re-entrant; different handles are independent.  Multi-GPU = one handle per device/process, sample
- *    ranges sharded by the caller, accumulation buffers summed with RCCL (see ptx_render_device).
+ *  - one handle = one GPU (the current HIP device at create time, or the one named to
+ *    ptx_scene_create_on).  Calls on one handle are not re-entrant; different handles are independent.
+ *    Multi-GPU inside one process = one handle per device and ptx_render_multi (sample ranges sharded over the
+ *    handles, per-GPU buffers summed with RCCL); across processes = one handle per process, ptx_shard_samples
+ *    + ptx_render_device + the caller's own RCCL reduce (bench.py, pathtracer_amd/parallel.py).
  *  - "host" pointers are ordinary memory; "device" pointers are HIP device memory on the handle's GPU.
  *  - there is no CPU fallback: without a usable HIP device every device call fails with PTX_E_HIP.
  */
@@ -223,12 +225,27 @@ int ptx_accum_load(const char* path, float* accum_rgb, uint32_t* width, uint32_t
 
 /* Upload a scene to the current HIP device. */
 int ptx_scene_create(const ptx_scene_desc* desc, uint32_t flags, ptx_scene** out);
+/* Same on HIP device `device` (the caller's current device is restored); ptx_device_count = visible GPUs.
+ * The reference's analogue of a device is a render thread (tracing/src/worker.rs:95-104). */
+int ptx_scene_create_on(const ptx_scene_desc* desc, uint32_t flags, int device, ptx_scene** out);
+int ptx_device_count(int* count);
+int ptx_scene_device(const ptx_scene* scene, int* device);
 void ptx_scene_destroy(ptx_scene* scene);
+/* Device memory behaviour (no counterpart in the reference).  Queues are allocated by the first render that
+ * needs them, sized for that call, and kept for the next; without ptx_set_queue_slots their budget is half of
+ * the device memory the scene could have when the call starts (free + already held by it).  ptx_scene_trim
+ * hands everything but the scene itself back to the device (the next render allocates again);
+ * ptx_scene_memory reports the bytes of render state held right now. */
+int ptx_scene_trim(ptx_scene* scene);
+int ptx_scene_memory(ptx_scene* scene, uint64_t* queue_bytes);
 
 /* `KdNode::intersect(&self, geometries, ray, t_range)` in bulk (kdtree/src/lib.rs:73-78) =
  * `GeometryCollection::intersect` (tracing/src/collections.rs:43-49).  Host buffers; synchronous. */
 int ptx_intersect_batch(ptx_scene* scene, const ptx_ray* rays, size_t n, ptx_hit* hits);
-/* Same with device-resident rays/hits, asynchronous on `stream` (a hipStream_t, NULL = default). */
+/* Same with device-resident rays/hits, asynchronous on `stream` (a hipStream_t, NULL = default).
+ * The *_batch_device calls of one handle share one work cursor and one stack-spill area, so the library
+ * serialises them: each call makes its stream wait for the event the previous call recorded, whatever the two
+ * streams are.  Launches of one handle therefore never overlap; use one handle per stream to overlap them. */
 int ptx_intersect_batch_device(ptx_scene* scene, const ptx_ray* d_rays, size_t n, ptx_hit* d_hits,
                                void* stream);
 /* Occlusion only: out[i] = 1 iff `intersect(ray, t_range).is_some()` — the only thing the integrator
@@ -250,6 +267,30 @@ int ptx_render(ptx_scene* scene, const ptx_pinhole* camera, uint64_t seed, uint3
  * multi-GPU driver calls before its RCCL reduce of the per-GPU buffers. */
 int ptx_render_device(ptx_scene* scene, const ptx_pinhole* camera, uint64_t seed, uint32_t first_sample,
                       uint32_t sample_count, float* d_accum, void* stream);
+/* `render_parallel_iterations` over SEVERAL GPUs in one process (tracing/src/worker.rs:84-119: T threads with
+ * private buffers, then `buffers.reduce(Add::add)`, :106-107): scenes[g] is the same scene uploaded to GPU g
+ * (ptx_scene_create_on).  Samples [first_sample, first_sample + sample_count) are cut into n_scenes contiguous
+ * ranges (ptx_shard_samples), one host thread per GPU renders its range into a device buffer of its own, the
+ * buffers are summed onto scenes[0]'s GPU and the result replaces accum_host (which goes in as the starting
+ * value of shard 0, so the image-buffer "add into" semantics hold and one scene gives the bits of ptx_render).
+ * reduce: PTX_REDUCE_AUTO = RCCL (`ncclReduce`, sum, root 0; librccl is loaded at first use) when the scenes
+ * sit on distinct GPUs, else PTX_REDUCE_PEER; PTX_REDUCE_RCCL forces RCCL (also with one scene: a one-rank
+ * communicator); PTX_REDUCE_PEER = peer copies to GPU 0 + an add kernel per shard, in shard order (the
+ * reference's left fold; also the only way when several scenes share a GPU).  progress is called from the
+ * render threads, one call at a time, with the samples completed over all shards.
+ * ptx_multi_last_reduce_ms: duration of the most recent reduce of this thread's ptx_render_multi call. */
+#define PTX_REDUCE_AUTO 0u
+#define PTX_REDUCE_RCCL 1u
+#define PTX_REDUCE_PEER 2u
+int ptx_render_multi(ptx_scene* const* scenes, uint32_t n_scenes, const ptx_pinhole* camera, uint64_t seed,
+                     uint32_t first_sample, uint32_t sample_count, float* accum_host, uint32_t reduce,
+                     ptx_progress_cb progress, void* user);
+int ptx_multi_last_reduce_ms(double* ms);
+/* The sample range of shard `shard` of `n_shards`: GPU g renders [first + g*S/N, first + (g+1)*S/N) — the
+ * contiguous form of the reference's "every thread renders iterations_per_thread full frames"
+ * (worker.rs:92-104).  Host arithmetic only. */
+int ptx_shard_samples(uint32_t first_sample, uint32_t sample_count, uint32_t n_shards, uint32_t shard,
+                      uint32_t* shard_first, uint32_t* shard_count);
 /* Samples per batch (0 = as many as the path-id and queue-slot budgets allow: one batch if possible).  A batch
  * is rendered as one sequence of rounds over its own queues; results do not depend on the batching. */
 int ptx_set_batch_samples(ptx_scene* scene, uint32_t samples_per_batch);
@@ -260,8 +301,9 @@ int ptx_set_batch_samples(ptx_scene* scene, uint32_t samples_per_batch);
 int ptx_render_region_device(ptx_scene* scene, const ptx_pinhole* camera, uint32_t x, uint32_t y, uint32_t width,
                              uint32_t height, uint64_t seed, uint32_t first_sample, uint32_t sample_count,
                              float* d_accum, void* stream);
-/* Queue slots (paths in flight) over all pipelines; 0 = default: what fits in 60 % of the device memory that
- * was free when the scene was created (162 bytes per slot with one light).  A batch with more paths
+/* Queue slots (paths in flight) over all pipelines; 0 = default: what fits in half of the device memory the
+ * scene could have when a render call starts (162 bytes per slot with one light).  Setting fewer slots than
+ * the scene holds releases its queues at once (ptx_scene_trim).  A batch with more paths
  * than slots is rendered with path regeneration: finished paths are replaced by the next camera rays of the
  * batch, so the memory stays bounded while every launch stays wide.  Results do not depend on it. */
 int ptx_set_queue_slots(ptx_scene* scene, uint64_t slots);

@@ -296,17 +296,21 @@ class LoadedScene:
         c = self.camera
         return Pinhole.new(c[0:3], c[3:6], c[6:9], float(c[9]), width, height)
 
-    def upload(self, flags=0):
-        return DeviceScene(self.desc, flags=flags, keepalive=self)
+    def upload(self, flags=0, device=None):
+        """Device-resident copy on the current HIP device, or on HIP device `device`."""
+        return DeviceScene(self.desc, flags=flags, keepalive=self, device=device)
 
 
 class DeviceScene:
     """A scene resident on the current HIP device: the `TriangleCollection` + `Pathtracer` state."""
 
-    def __init__(self, desc, flags=0, keepalive=None):
+    def __init__(self, desc, flags=0, keepalive=None, device=None):
         self._h = C.c_void_p()
         self._keep = keepalive
-        _check(lib().ptx_scene_create(C.byref(desc), flags, C.byref(self._h)))
+        if device is None:
+            _check(lib().ptx_scene_create(C.byref(desc), flags, C.byref(self._h)))
+        else:
+            _check(lib().ptx_scene_create_on(C.byref(desc), flags, int(device), C.byref(self._h)))
         self.max_bounces = desc.max_bounces
         self.n_lights = desc.n_lights
         self._raylog_cap = 0
@@ -391,6 +395,22 @@ class DeviceScene:
     def set_pipelines(self, n):
         _check(lib().ptx_set_pipelines(self._h, n))
 
+    def trim(self):
+        """Hands the queues and staging buffers back to the device (the next render allocates again)."""
+        _check(lib().ptx_scene_trim(self._h))
+
+    def memory(self):
+        """Bytes of render state (queues, radiance, stacks) held right now."""
+        b = C.c_uint64()
+        _check(lib().ptx_scene_memory(self._h, C.byref(b)))
+        return b.value
+
+    @property
+    def device(self):
+        d = C.c_int()
+        _check(lib().ptx_scene_device(self._h, C.byref(d)))
+        return d.value
+
     def render(self, pinhole, sample_count, seed=0, first_sample=0, accum=None, progress=None):
         """Adds samples [first_sample, first_sample+sample_count) into accum (H x W x 3 float32)."""
         if accum is None:
@@ -460,6 +480,42 @@ class DeviceScene:
         return {"extend": dict(zip(keys, (int(x) for x in raw[:12]))), "shadow": dict(zip(keys, (int(x) for x in raw[12:])))}
 
 
+REDUCE_AUTO, REDUCE_RCCL, REDUCE_PEER = 0, 1, 2
+
+
+def device_count():
+    n = C.c_int()
+    _check(lib().ptx_device_count(C.byref(n)))
+    return n.value
+
+
+def shard_samples(first_sample, sample_count, n_shards, shard):
+    """(first, count) of shard `shard`: GPU g renders [first + g*S/N, first + (g+1)*S/N) (ptx_shard_samples)."""
+    a, b = C.c_uint32(), C.c_uint32()
+    _check(lib().ptx_shard_samples(first_sample, sample_count, n_shards, shard, C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def render_multi(scenes, pinhole, sample_count, seed=0, first_sample=0, accum=None, reduce=REDUCE_AUTO, progress=None):
+    """`render_parallel_iterations` over several GPUs of this process (ptx_render_multi): scenes[g] lives on
+    GPU g; adds samples [first_sample, first_sample+sample_count) into accum (H x W x 3 float32)."""
+    if accum is None:
+        accum = np.zeros((pinhole.height, pinhole.width, 3), np.float32)
+    assert accum.dtype == np.float32 and accum.flags.c_contiguous and accum.size == pinhole.width * pinhole.height * 3
+    handles = (C.c_void_p * len(scenes))(*[s._h for s in scenes])
+    cb_t = C.CFUNCTYPE(None, C.c_uint32, C.c_double, C.c_void_p)
+    cb = cb_t(lambda done, secs, _u: progress(done, secs)) if progress else C.cast(None, cb_t)
+    _check(lib().ptx_render_multi(handles, len(scenes), C.byref(pinhole), C.c_uint64(seed), first_sample, sample_count,
+                                  _ptr(accum), reduce, cb, None))
+    return accum
+
+
+def multi_last_reduce_ms():
+    ms = C.c_double()
+    _check(lib().ptx_multi_last_reduce_ms(C.byref(ms)))
+    return ms.value
+
+
 def to_rgb8(accum, iterations):
     """`ImageBuffer::to_rgb8(iterations as u16)`."""
     a = np.ascontiguousarray(accum, np.float32)
@@ -502,11 +558,15 @@ def read_png_linear(path):
 
 def render_parallel_iterations(scene, pinhole, threads, iterations_per_thread, seed=0, progress=None):
     """`render_parallel_iterations` (tracing/src/worker.rs:84-119): threads x iterations_per_thread
-    full-frame samples on ONE GPU; returns (seconds, rgb8 image).  The GPU plays every thread."""
+    full-frame samples; returns (seconds, rgb8 image).  `scene` is one DeviceScene (one GPU plays every
+    thread) or a list of them, one per GPU (the samples are sharded over the GPUs, ptx_render_multi)."""
     import time
 
     total = threads * iterations_per_thread
     t0 = time.perf_counter()
-    accum = scene.render(pinhole, total, seed=seed, progress=progress)
+    if isinstance(scene, (list, tuple)):
+        accum = render_multi(scene, pinhole, total, seed=seed, progress=progress)
+    else:
+        accum = scene.render(pinhole, total, seed=seed, progress=progress)
     secs = time.perf_counter() - t0
     return secs, to_rgb8(accum, total)

@@ -3,11 +3,11 @@
 // libptx_mi355x.so.  `-t threads` x `-n iterations-per-thread` keeps its meaning as the total sample
 // count (there is no global spp flag in the reference, tracing/src/worker.rs:92); the GPU plays all threads.
 // Extra long flags (not in the reference): --seed N, --device D, --batch-samples S, --stats, --checkpoint FILE / --resume FILE
-// (accumulation buffer save / continue), and
+// (accumulation buffer save / continue), --gpus N [--reduce rccl|peer] [--share-device] (the iterations are
+// sharded over N GPUs, devices D .. D+N-1, and the per-GPU buffers summed with RCCL: ptx_render_multi; with
+// --share-device all N shards run on device D, the rehearsal a one-GPU machine can do), and
 // --ray-log FILE [--ray-log-max N]: what the reference writes to ./tmp/raylog0.bin when built with its
 // `ray_logging` feature (raylogger.rs), for all iterations, as one thread would.
-#include <hip/hip_runtime_api.h>
-
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -29,6 +29,9 @@ struct Args {
     int device = 0;
     uint32_t batch_samples = 0;
     bool stats = false;
+    uint32_t gpus = 1;
+    uint32_t reduce = PTX_REDUCE_AUTO;
+    bool share_device = false;
     std::string ray_log, checkpoint, resume;
     uint64_t ray_log_max = 1ull << 26;  // records held on the device per iteration
 };
@@ -46,6 +49,7 @@ struct Args {
             "      --intersect-cost <F>               SAH kd-tree intersect cost [default: 1.5]\n"
             "      --empty-factor <F>                 SAH kd-tree empty factor [default: 0.8]\n"
             "      --seed <N> --device <D> --batch-samples <S> --stats   (MI355X extras)\n"
+            "      --gpus <N> [--reduce rccl|peer] [--share-device]      shard the iterations over N GPUs, sum with RCCL\n"
             "      --ray-log <FILE> [--ray-log-max <RECORDS>]           33-byte ray records (raylogger.rs)\n"
             "      --checkpoint <FILE>                save the accumulation buffer after the render\n"
             "      --resume <FILE>                    continue a saved buffer (its seed; iterations are added)\n",
@@ -109,6 +113,15 @@ int main(int argc, char** argv) {
         else if (k == "--device") a.device = atoi(val());
         else if (k == "--batch-samples") a.batch_samples = (uint32_t)strtoul(val(), nullptr, 10);
         else if (k == "--stats") a.stats = true;
+        else if (k == "--gpus") a.gpus = (uint32_t)strtoul(val(), nullptr, 10);
+        else if (k == "--share-device") a.share_device = true;
+        else if (k == "--reduce") {
+            const std::string r = val();
+            if (r == "rccl") a.reduce = PTX_REDUCE_RCCL;
+            else if (r == "peer") a.reduce = PTX_REDUCE_PEER;
+            else if (r == "auto") a.reduce = PTX_REDUCE_AUTO;
+            else usage("--reduce takes rccl, peer or auto");
+        }
         else if (k == "--ray-log") a.ray_log = val();
         else if (k == "--checkpoint") a.checkpoint = val();
         else if (k == "--resume") a.resume = val();
@@ -118,6 +131,8 @@ int main(int argc, char** argv) {
     if (a.input.empty()) usage("the following required arguments were not provided: --input <INPUT>");
     if (a.output.empty()) usage("the following required arguments were not provided: --output <OUTPUT>");
     if (a.max_bounces > 255) usage("max-bounces is a u8");
+    if (a.gpus < 1 || a.gpus > 64) usage("--gpus takes 1..64");
+    if (a.gpus > 1 && !a.ray_log.empty()) usage("--ray-log writes one thread's file: use one GPU");
 
     auto die = [](const char* what) {
         fprintf(stderr, "%s: %s\n", what, ptx_last_error());
@@ -131,16 +146,24 @@ int main(int argc, char** argv) {
     ptx_loaded_camera(loaded, cam);
     ptx_pinhole pinhole;
     if (ptx_pinhole_make(cam, cam + 3, cam + 6, cam[9], a.width, a.height, &pinhole)) die("camera");
-    if (hipSetDevice(a.device) != hipSuccess) {
-        fprintf(stderr, "no usable HIP device %d (this build has no CPU fallback)\n", a.device);
+    int n_devices = 0;
+    ptx_device_count(&n_devices);
+    const uint32_t need = a.share_device ? 1u : a.gpus;
+    if (a.device < 0 || (uint32_t)a.device + need > (uint32_t)n_devices) {
+        fprintf(stderr, "no usable HIP device(s) %d..%u: %d visible (this build has no CPU fallback)\n", a.device,
+                (uint32_t)a.device + need - 1, n_devices);
         return 1;
     }
-    ptx_scene* scene = nullptr;
-    if (ptx_scene_create(&desc, a.stats ? PTX_FLAG_TIME_KERNELS : 0, &scene)) die("upload");
-    if (a.batch_samples) ptx_set_batch_samples(scene, a.batch_samples);
+    std::vector<ptx_scene*> scenes(a.gpus, nullptr);  // the scene replicated on every GPU
+    for (uint32_t g = 0; g < a.gpus; ++g) {
+        if (ptx_scene_create_on(&desc, a.stats ? PTX_FLAG_TIME_KERNELS : 0, a.device + (a.share_device ? 0 : (int)g), &scenes[g])) die("upload");
+        if (a.batch_samples) ptx_set_batch_samples(scenes[g], a.batch_samples);
+    }
+    ptx_scene* scene = scenes[0];
 
     const uint32_t total = a.threads * a.iterations_per_thread;
     printf("Rendering %ux%u px image with %u thread(s) and %u total iteration(s)...\n", a.width, a.height, a.threads, total);
+    if (a.gpus > 1) printf("Sharding the iterations over %u GPU(s)%s\n", a.gpus, a.share_device ? " (all on one device)" : "");
     std::vector<float> accum((size_t)a.width * a.height * 3, 0.0f);
     uint32_t first = 0;  // samples already in the buffer
     if (!a.resume.empty()) {
@@ -150,7 +173,9 @@ int main(int argc, char** argv) {
     }
     Progress prog{a.threads, total};
     auto t0 = std::chrono::steady_clock::now();
-    if (a.ray_log.empty()) {
+    if (a.gpus > 1) {
+        if (ptx_render_multi(scenes.data(), a.gpus, &pinhole, a.seed, first, total, accum.data(), a.reduce, on_progress, &prog)) die("render");
+    } else if (a.ray_log.empty()) {
         if (ptx_render(scene, &pinhole, a.seed, first, total, accum.data(), on_progress, &prog)) die("render");
     } else {  // one iteration at a time, so that the log of one iteration is all the device has to hold
         FILE* f = fopen(a.ray_log.c_str(), "wb");
@@ -174,9 +199,19 @@ int main(int argc, char** argv) {
     }
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     printf("\nTotal time: %.2fs\n", secs);
+    if (a.gpus > 1) {
+        double ms = 0;
+        ptx_multi_last_reduce_ms(&ms);
+        printf("Reduce over %u GPU(s): %.2f ms\n", a.gpus, ms);
+    }
     if (a.stats) {
-        ptx_counters c;
-        ptx_stats(scene, &c);
+        ptx_counters c{};
+        for (ptx_scene* s : scenes) {  // sums over the GPUs; the kernel times add up across devices
+            ptx_counters k;
+            ptx_stats(s, &k);
+            c.samples += k.samples, c.extend_rays += k.extend_rays, c.shadow_rays += k.shadow_rays;
+            c.extend_ms += k.extend_ms, c.shadow_ms += k.shadow_ms, c.shade_ms += k.shade_ms, c.generate_ms += k.generate_ms;
+        }
         printf("  samples: %llu (%.3f Msamples/s)\n  extend rays: %llu in %.1f ms (%.1f Mrays/s)\n  shadow rays: %llu in %.1f ms (%.1f Mrays/s)\n"
                "  shade %.1f ms, generate %.1f ms\n",
                (unsigned long long)c.samples, c.samples / secs / 1e6, (unsigned long long)c.extend_rays, c.extend_ms,
@@ -189,7 +224,7 @@ int main(int argc, char** argv) {
     std::vector<uint8_t> rgb(accum.size());
     ptx_tonemap_rgb8(accum.data(), a.width, a.height, first + total, rgb.data());
     if (ptx_png_write_rgb8(a.output.c_str(), rgb.data(), a.width, a.height)) die("write");
-    ptx_scene_destroy(scene);
+    for (ptx_scene* s : scenes) ptx_scene_destroy(s);
     ptx_loaded_free(loaded);
     return 0;
 }

@@ -21,12 +21,14 @@
 #include <cstring>
 #include <chrono>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/ptx.h"
 #include "../../include/ptx_sampling.h"
 #include "host_internal.hpp"
+#include "device_internal.hpp"
 #include "traverse.hpp"
 
 using namespace ptx;
@@ -235,6 +237,9 @@ constexpr uint32_t REFILL_IDLE = PTX_REFILL_IDLE;
 constexpr uint32_t TRI_BATCH_NEAREST = PTX_TRI_BATCH;  // lanes that must wait in a leaf before the triangle step runs
 constexpr uint32_t TRI_BATCH_ANYHIT = PTX_TRI_BATCH_ANY;
 
+#ifndef PTX_AUTO_MEMORY_FRACTION
+#define PTX_AUTO_MEMORY_FRACTION 0.5
+#endif
 constexpr int32_t DESC_EXIT = -1, DESC_IDLE = -2;
 constexpr uint32_t DESC_LEAF = 0x80000000u, DESC_PAYLOAD = 0x3FFFFFFFu;
 constexpr uint32_t DESC_MAX_PAYLOAD = 0x3FFFFFFDu;  // offsets and triangle indices stay below 2^30 - 2
@@ -1066,7 +1071,7 @@ struct ptx_scene {
     // render state (allocated on first render, grown on demand)
     uint32_t batch_samples = 0;  // 0 = choose from the image size
     uint64_t slot_budget = 0;    // queue slots over all pipelines (ptx_set_queue_slots, PTX_SLOTS_MI = Mi slots); 0 = from auto_bytes
-    uint64_t auto_bytes = 0;     // 60 % of the device memory that was free when the scene was created
+    uint64_t auto_bytes = 0;     // fallback for auto_queue_bytes(): a share of the memory that was free at create time
     size_t cap_slots = 0, cap_paths = 0;
     uint32_t cap_rounds = 0, last_rounds = 0;
     // One pipeline = the queues and state of one sample batch in flight on its own stream.  Batches are
@@ -1106,6 +1111,13 @@ struct ptx_scene {
     hipEvent_t ev_fork = nullptr;
     DevBuf<uint2> spill;  // of the *_batch entry points
     DevBuf<uint32_t> batch_cursor;
+    // The *_batch_device entry points share that one cursor and spill area, so their launches are serialised:
+    // every call waits for the event its predecessor recorded, whatever streams the two were given.
+    hipEvent_t ev_batch = nullptr;
+    bool batch_pending = false;
+    // ptx_render_multi (ptx_multi.hip): this shard's accumulation buffer, a landing buffer for a peer's, a stream
+    DevBuf<float> multi_accum, multi_tmp;
+    hipStream_t multi_stream = nullptr;
     DevBuf<unsigned long long> totals;
     DevBuf<FailRec> fails;                   // PTX_FLAG_CHECK_BRUTE
     DevBuf<unsigned long long> check_count;  // [2] rays checked, fails found
@@ -1134,6 +1146,8 @@ struct ptx_scene {
 
     ~ptx_scene() {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_batch) (void)hipEventDestroy(ev_batch);
+        if (multi_stream) (void)hipStreamDestroy(multi_stream);
         for (auto& s : stamps) {
             (void)hipEventDestroy(s.a);
             (void)hipEventDestroy(s.b);
@@ -1175,6 +1189,24 @@ struct Timed {  // RAII bracket of one launch with two events when timing is on
         }
     }
 };
+
+// Without anybody asking for ptx_stats a long-running render loop would pile up stamps (two events per launch):
+// past a threshold the finished ones are folded into the class totals and their events recycled.
+void clear_stale_stamps(ptx_scene* sc) {
+    if (sc->stamps.size() < 4096) return;
+    size_t kept = 0;
+    for (auto& s : sc->stamps) {
+        float ms = 0.0f;
+        if (hipEventQuery(s.b) == hipSuccess) {
+            if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) sc->class_ms[s.cls] += ms;
+            sc->free_events.push_back(s.a);
+            sc->free_events.push_back(s.b);
+        } else {
+            sc->stamps[kept++] = s;
+        }
+    }
+    sc->stamps.resize(kept);
+}
 
 void resolve_stamps(ptx_scene* sc) {
     for (auto& s : sc->stamps) {
@@ -1336,7 +1368,7 @@ struct SegRange {  // a segmented queue as the traversal kernel sees it (see Ren
 
 template <bool ANY>
 int launch_traverse(ptx_scene* sc, const ptx_ray* d_rays, const SegRange& sr, uint32_t n, ptx_hit* d_hits, uint8_t* d_occ,
-                    uint32_t* d_cursor, uint2* d_spill, unsigned long long* work, hipStream_t stream) {
+                    uint32_t* d_cursor, uint2* d_spill, unsigned long long* work, hipStream_t stream, int max_grid = 0) {
     const bool count = (sc->flags & PTX_FLAG_COUNT_WORK) != 0 && work;
     TravArgs a{};
     a.nodes = sc->dev_nodes.p;
@@ -1355,10 +1387,11 @@ int launch_traverse(ptx_scene* sc, const ptx_ray* d_rays, const SegRange& sr, ui
     a.occ = d_occ;
     a.cursor = d_cursor;
     a.spill = d_spill;
-    a.spill_stride = (uint32_t)sc->tgrid * TBLOCK;
+    // the spill area is sized for this many workgroups: never launch more
+    int grid = max_grid > 0 && max_grid < sc->tgrid ? max_grid : sc->tgrid;
+    a.spill_stride = (uint32_t)grid * TBLOCK;
     a.work = work;
     a.prof = sc->totals.p + (ANY ? 20 : 8);
-    int grid = sc->tgrid;  // the spill area is sized for this many threads: never launch more
     if (!sr.counts) {
         int need = (int)((n + 63) / 64 + (TBLOCK / 64) - 1) / (TBLOCK / 64);
         if (need < grid) grid = need > 0 ? need : 1;
@@ -1386,6 +1419,29 @@ void launch_check(ptx_scene* sc, const ptx_ray* rays, const SegRange& sr, const 
     c.fail_cap = ptx_scene::FAIL_CAP;
     c.counters = sc->check_count.p;
     k_check<<<(int)sr.n_seg, BLOCK, 0, stream>>>(c);
+}
+
+// Bytes of render state (queues, per-path radiance, stacks) the scene holds right now.
+uint64_t held_queue_bytes(const ptx_scene* sc) {
+    uint64_t b = 0;
+    for (const auto& up : sc->pipes) {
+        if (!up) continue;
+        const ptx_scene::Pipe& p = *up;
+        b += (p.rays[0].n + p.rays[1].n + p.sh_rays.n) * sizeof(ptx_ray) + p.hits.n * sizeof(ptx_hit);
+        b += (p.transq[0].n + p.transq[1].n + p.sh_T.n + p.sh_contrib.n) * sizeof(float4) + p.radiance.n * sizeof(Rad);
+        b += p.sh_occ.n + p.sh_bounce.n + (p.spill.n + p.spill2.n) * sizeof(uint2) + (p.counts.n + p.segs.n) * sizeof(uint32_t);
+    }
+    return b;
+}
+
+// Default queue budget (no ptx_set_queue_slots): HALF of the device memory this scene could have at the time of
+// the call - what is free now plus what the scene already holds - so that a second handle on the same GPU, or
+// buffers a caller allocates later (RCCL, its own images), still find room; the rest of the budget logic
+// (halving on an allocation failure) stays as the safety net.
+uint64_t auto_queue_bytes(const ptx_scene* sc) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return sc->auto_bytes;
+    return (uint64_t)((free_b + held_queue_bytes(sc)) * PTX_AUTO_MEMORY_FRACTION);
 }
 
 }  // namespace
@@ -1442,7 +1498,7 @@ int ptx_scene_create(const ptx_scene_desc* d, uint32_t flags, ptx_scene** out) {
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)64 << 30;
-        sc->auto_bytes = (uint64_t)(free_b * 0.6);
+        sc->auto_bytes = (uint64_t)(free_b * PTX_AUTO_MEMORY_FRACTION);  // only used if hipMemGetInfo fails later
     }
     if (const char* e = getenv("PTX_OVERLAP")) sc->overlap_shadow = atoi(e) != 0;
     if (const char* e = getenv("PTX_SLOTS_MI")) {
@@ -1522,12 +1578,38 @@ int ptx_scene_create(const ptx_scene_desc* d, uint32_t flags, ptx_scene** out) {
     HIP_TRY(hipMemset(sc->totals.p, 0, 32 * sizeof(unsigned long long)));
     HIP_TRY(sc->spill.ensure((size_t)(PTX_MAX_DEPTH - LDS_DEPTH) * sc->tgrid * TBLOCK));
     HIP_TRY(sc->batch_cursor.ensure(1));
+    HIP_TRY(hipEventCreateWithFlags(&sc->ev_batch, hipEventDisableTiming));
     if (flags & PTX_FLAG_CHECK_BRUTE) {
         HIP_TRY(sc->fails.ensure(ptx_scene::FAIL_CAP));
         HIP_TRY(sc->check_count.ensure(2));
         HIP_TRY(hipMemset(sc->check_count.p, 0, 2 * sizeof(unsigned long long)));
     }
     *out = sc.release();
+    return PTX_OK;
+}
+
+int ptx_device_count(int* count) {
+    if (!count) return fail(PTX_E_ARG, "ptx_device_count: null argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return PTX_OK;
+}
+
+int ptx_scene_create_on(const ptx_scene_desc* d, uint32_t flags, int device, ptx_scene** out) {
+    int n = 0, before = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(PTX_E_HIP, "ptx_scene_create_on: no HIP device available");
+    if (device < 0 || device >= n) return fail(PTX_E_ARG, "ptx_scene_create_on: no such device");
+    HIP_TRY(hipGetDevice(&before));
+    HIP_TRY(hipSetDevice(device));
+    const int rc = ptx_scene_create(d, flags, out);
+    (void)hipSetDevice(before);
+    return rc;
+}
+
+int ptx_scene_device(const ptx_scene* scene, int* device) {
+    if (!scene || !device) return fail(PTX_E_ARG, "ptx_scene_device: null argument");
+    *device = scene->device;
     return PTX_OK;
 }
 
@@ -1544,12 +1626,18 @@ int ptx_intersect_batch_device(ptx_scene* sc, const ptx_ray* d_rays, size_t n, p
     if (n == 0) return PTX_OK;
     if (!d_rays || !d_hits) return fail(PTX_E_ARG, "ptx_intersect_batch_device: null buffer");
     if (n > 0xFFFFFFFFull) return fail(PTX_E_LIMIT, "ptx_intersect_batch_device: more than 2^32-1 rays in one call");
-    Timed tm(sc, (hipStream_t)stream, KC_EXTEND);
-    sc->batch_extend_rays += n;
-    ++sc->extend_launches;
-    HIP_TRY(hipMemsetAsync(sc->batch_cursor.p, 0, sizeof(uint32_t), (hipStream_t)stream));
-    return launch_traverse<false>(sc, d_rays, SegRange{}, (uint32_t)n, d_hits, nullptr, sc->batch_cursor.p, sc->spill.p,
-                                  sc->totals.p + 2, (hipStream_t)stream);
+    if (sc->batch_pending) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, sc->ev_batch, 0));  // see ptx_scene::ev_batch
+    {
+        Timed tm(sc, (hipStream_t)stream, KC_EXTEND);
+        sc->batch_extend_rays += n;
+        ++sc->extend_launches;
+        HIP_TRY(hipMemsetAsync(sc->batch_cursor.p, 0, sizeof(uint32_t), (hipStream_t)stream));
+        rc = launch_traverse<false>(sc, d_rays, SegRange{}, (uint32_t)n, d_hits, nullptr, sc->batch_cursor.p, sc->spill.p,
+                                    sc->totals.p + 2, (hipStream_t)stream);
+    }
+    HIP_TRY(hipEventRecord(sc->ev_batch, (hipStream_t)stream));
+    sc->batch_pending = true;
+    return rc;
 }
 
 int ptx_occluded_batch_device(ptx_scene* sc, const ptx_ray* d_rays, size_t n, uint8_t* d_out, void* stream) {
@@ -1558,12 +1646,18 @@ int ptx_occluded_batch_device(ptx_scene* sc, const ptx_ray* d_rays, size_t n, ui
     if (n == 0) return PTX_OK;
     if (!d_rays || !d_out) return fail(PTX_E_ARG, "ptx_occluded_batch_device: null buffer");
     if (n > 0xFFFFFFFFull) return fail(PTX_E_LIMIT, "ptx_occluded_batch_device: more than 2^32-1 rays in one call");
-    Timed tm(sc, (hipStream_t)stream, KC_SHADOW);
-    sc->batch_shadow_rays += n;
-    ++sc->shadow_launches;
-    HIP_TRY(hipMemsetAsync(sc->batch_cursor.p, 0, sizeof(uint32_t), (hipStream_t)stream));
-    return launch_traverse<true>(sc, d_rays, SegRange{}, (uint32_t)n, nullptr, d_out, sc->batch_cursor.p, sc->spill.p,
-                                 sc->totals.p + 4, (hipStream_t)stream);
+    if (sc->batch_pending) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, sc->ev_batch, 0));
+    {
+        Timed tm(sc, (hipStream_t)stream, KC_SHADOW);
+        sc->batch_shadow_rays += n;
+        ++sc->shadow_launches;
+        HIP_TRY(hipMemsetAsync(sc->batch_cursor.p, 0, sizeof(uint32_t), (hipStream_t)stream));
+        rc = launch_traverse<true>(sc, d_rays, SegRange{}, (uint32_t)n, nullptr, d_out, sc->batch_cursor.p, sc->spill.p,
+                                   sc->totals.p + 4, (hipStream_t)stream);
+    }
+    HIP_TRY(hipEventRecord(sc->ev_batch, (hipStream_t)stream));
+    sc->batch_pending = true;
+    return rc;
 }
 
 int ptx_intersect_batch(ptx_scene* sc, const ptx_ray* rays, size_t n, ptx_hit* hits) {
@@ -1594,6 +1688,29 @@ int ptx_set_queue_slots(ptx_scene* sc, uint64_t slots) {
     if (!sc) return fail(PTX_E_ARG, "ptx_set_queue_slots: null scene");
     if (slots >= (1ull << 32)) return fail(PTX_E_LIMIT, "ptx_set_queue_slots: at most 2^32 - 1 slots");
     sc->slot_budget = slots;
+    // a smaller budget than what is held takes effect now: the queues are released and rebuilt by the next render
+    if (slots && (uint64_t)sc->cap_slots * sc->pipes.size() > slots) return ptx_scene_trim(sc);
+    return PTX_OK;
+}
+
+int ptx_scene_trim(ptx_scene* sc) {
+    int rc = check_scene(sc, "ptx_scene_trim");
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    sc->pipes.clear();
+    sc->cap_slots = sc->cap_paths = 0;
+    sc->cap_rounds = 0;
+    sc->stage_rays.release();
+    sc->stage_hits.release();
+    sc->stage_accum.release();
+    sc->multi_accum.release();
+    sc->multi_tmp.release();
+    return PTX_OK;
+}
+
+int ptx_scene_memory(ptx_scene* sc, uint64_t* queue_bytes) {
+    if (!sc || !queue_bytes) return fail(PTX_E_ARG, "ptx_scene_memory: null argument");
+    *queue_bytes = held_queue_bytes(sc);
     return PTX_OK;
 }
 
@@ -1613,6 +1730,7 @@ struct Region {
 static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uint32_t first_sample,
                        uint32_t sample_count, float* d_accum, hipStream_t user_stream, ptx_progress_cb progress,
                        void* user, const Region* region = nullptr) {
+    clear_stale_stamps(sc);
     if (!cam || !d_accum) return fail(PTX_E_ARG, "ptx_render: null argument");
     if (!sc->shading) return fail(PTX_E_ARG, "ptx_render: scene was created without shading data");
     if (cam->width == 0 || cam->height == 0) return fail(PTX_E_ARG, "ptx_render: empty image");
@@ -1635,7 +1753,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
     const uint32_t B = sc->dev.max_bounces, L = sc->dev.n_lights;
     // bytes per queue slot (see ensure_render_state) + the radiance of up to two paths per slot
     const uint64_t slot_bytes = 129 + (uint64_t)(L ? L : 1u) * (33 + (L > 1 ? 16 : 0)) + 24;
-    uint64_t slot_budget = (sc->slot_budget ? sc->slot_budget : sc->auto_bytes / slot_bytes) / n_pipes;
+    uint64_t slot_budget = (sc->slot_budget ? sc->slot_budget : auto_queue_bytes(sc) / slot_bytes) / n_pipes;
     const uint64_t max_batch_paths = (1ull << 31) - (1ull << 20);
     uint32_t S = 1, n_seg = 1, seg_range = 1, seg_cap = 64, rounds = 0;
     uint32_t want_S = sc->batch_samples;  // samples per batch, 0 = choose
@@ -1666,10 +1784,19 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         if (n_seg < 1) n_seg = 1;
         seg_range = (uint32_t)((batch_paths + n_seg - 1) / n_seg);
         seg_cap = (uint32_t)((seg_range + 63) / 64 * 64);
-        {
+        if (slot_budget < (uint64_t)n_seg * seg_cap) {
+            // the budget bounds the slots: fewer segments when it is under 64 slots per segment, then
+            // narrower segments (path regeneration covers the rest of each segment's range)
+            if (slot_budget / n_seg < 64) {
+                n_seg = (uint32_t)(slot_budget / 64 > 0 ? slot_budget / 64 : 1);
+                seg_range = (uint32_t)((batch_paths + n_seg - 1) / n_seg);
+                seg_cap = (uint32_t)((seg_range + 63) / 64 * 64);
+            }
             const uint64_t by_budget = slot_budget / n_seg / 64 * 64;
-            if (by_budget >= 64 && by_budget < seg_cap) seg_cap = (uint32_t)by_budget;
+            if (by_budget < seg_cap) seg_cap = (uint32_t)(by_budget >= 64 ? by_budget : 64);
         }
+        if ((uint64_t)n_seg * seg_cap > index_limit)
+            return fail(PTX_E_LIMIT, "ptx_render: queue slots x lights beyond the 32-bit index range (lower ptx_set_batch_samples or ptx_set_queue_slots)");
         // a slot turns over after at most B rounds: B x ceil(range / cap) rounds start and finish every path
         rounds = B * ((seg_range + seg_cap - 1) / seg_cap);
         const int rc = ensure_render_state(sc, (size_t)n_seg * seg_cap, (size_t)batch_paths, rounds);
@@ -1690,6 +1817,9 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
     for (auto& p : sc->pipes) HIP_TRY(hipStreamWaitEvent(p->stream, sc->ev_fork, 0));
     hipEvent_t prev_accum = nullptr;
     uint32_t batch_no = 0;
+    // the batches run inside a lambda so that EVERY way out of them, errors included, passes the join below:
+    // the caller's stream must never be left without its dependency on the forked pipelines
+    auto run_batches = [&]() -> int {
     for (uint32_t done = 0; done < sample_count; done += S, ++batch_no) {
         ptx_scene::Pipe& p = *sc->pipes[batch_no % sc->pipes.size()];
         sc->last_pipe = (int)(batch_no % sc->pipes.size());
@@ -1806,13 +1936,47 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
             progress(done + ns, secs, user);
         }
     }
-    // join: the caller's stream continues after every pipeline has drained
+    return PTX_OK;
+    };
+    rc = run_batches();
+    // join: the caller's stream continues after every pipeline has drained (after an error too: whatever was
+    // launched before it still runs, and the second stream of a pipeline may not have been joined to the first)
     for (auto& p : sc->pipes) {
-        HIP_TRY(hipEventRecord(p->ev_join, p->stream));
-        HIP_TRY(hipStreamWaitEvent(user_stream, p->ev_join, 0));
+        if (rc != PTX_OK && sc->overlap_shadow) {
+            (void)hipEventRecord(p->ev_resolve, p->stream2);
+            (void)hipStreamWaitEvent(p->stream, p->ev_resolve, 0);
+        }
+        const hipError_t e1 = hipEventRecord(p->ev_join, p->stream);
+        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(user_stream, p->ev_join, 0) : e1;
+        if (e2 != hipSuccess && rc == PTX_OK) rc = hip_fail(e2, "ptx_render: joining the pipelines");
     }
+    return rc;
+}
+
+}  // extern "C"
+
+namespace ptx {
+int internal_render(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uint32_t first_sample, uint32_t sample_count,
+                    float* d_accum, void* stream, ptx_progress_cb progress, void* user) {
+    int rc = check_scene(sc, "ptx_render_multi");
+    if (rc) return rc;
+    return render_impl(sc, cam, seed, first_sample, sample_count, d_accum, (hipStream_t)stream, progress, user);
+}
+int internal_device(const ptx_scene* sc) { return sc->device; }
+int internal_multi_slot(ptx_scene* sc, size_t n_floats, float** accum, float** tmp, void** stream) {
+    int rc = check_scene(sc, "ptx_render_multi");
+    if (rc) return rc;
+    if (!sc->multi_stream) HIP_TRY(hipStreamCreateWithFlags(&sc->multi_stream, hipStreamNonBlocking));
+    HIP_TRY(sc->multi_accum.ensure(n_floats));
+    if (tmp) HIP_TRY(sc->multi_tmp.ensure(n_floats));
+    *accum = sc->multi_accum.p;
+    if (tmp) *tmp = sc->multi_tmp.p;
+    *stream = sc->multi_stream;
     return PTX_OK;
 }
+}  // namespace ptx
+
+extern "C" {
 
 int ptx_render_device(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uint32_t first_sample,
                       uint32_t sample_count, float* d_accum, void* stream) {

@@ -13,9 +13,9 @@ def shard_samples(total_samples, world_size, rank):
     """Contiguous sample range [first, first+count) of `rank` (GPU g gets [g*S/N, (g+1)*S/N))."""
     if world_size <= 0 or not (0 <= rank < world_size):
         raise ValueError("bad rank/world_size")
-    first = (total_samples * rank) // world_size
-    last = (total_samples * (rank + 1)) // world_size
-    return first, last - first
+    from . import shard_samples as _abi_shard  # one definition: ptx_shard_samples of the C ABI
+
+    return _abi_shard(0, total_samples, world_size, rank)
 
 
 def render_sharded(render_fn, total_samples, accum, first_sample=0, group=None, dst=0):

@@ -254,3 +254,35 @@ def test_accum_checkpoint_round_trip_and_damage(tmp_path):
     w, h = C.c_uint32(16), C.c_uint32(13)
     buf = np.zeros((13, 16, 3), np.float32)
     assert pt.lib().ptx_accum_load(os.fsencode(path), buf.ctypes.data_as(C.c_void_p), C.byref(w), C.byref(h), None, None) == -1  # PTX_E_ARG
+
+
+def test_shard_samples_tiles_the_range_exactly():
+    """ptx_shard_samples (worker.rs:92-104 as contiguous ranges): GPU g renders [first + g*S/N, first + (g+1)*S/N)."""
+    for first, count, n in [(0, 1024, 8), (5, 7, 3), (0, 2, 4), (100, 0, 2), (0, 4096, 7), (2**32 - 11, 10, 4)]:
+        at = first
+        for g in range(n):
+            f, c = pt.shard_samples(first, count, n, g)
+            assert f == at and c in (count // n, count // n + 1)
+            at = f + c
+        assert at == first + count
+    for bad in [(0, 10, 0, 0), (0, 10, 2, 2), (2**32 - 5, 10, 2, 0)]:
+        with pytest.raises(pt.PtxError):
+            pt.shard_samples(*bad)
+    from pathtracer_amd.parallel import shard_samples  # the per-process path uses the same definition
+
+    assert [shard_samples(10, 4, r) for r in range(4)] == [(0, 2), (2, 3), (5, 2), (7, 3)]
+
+
+def test_render_multi_rejects_bad_arguments_before_touching_a_gpu():
+    L = pt.lib()
+    ph = pt.Pinhole()
+    ph.width = ph.height = 4
+    acc = np.zeros(48, f32)
+    none = (C.c_void_p * 1)(None)
+    assert L.ptx_render_multi(None, 0, C.byref(ph), C.c_uint64(0), 0, 1, acc.ctypes.data_as(C.c_void_p), 0, None, None) == -1
+    assert L.ptx_render_multi(none, 1, C.byref(ph), C.c_uint64(0), 0, 1, acc.ctypes.data_as(C.c_void_p), 0, None, None) == -1
+    assert L.ptx_render_multi(none, 1, C.byref(ph), C.c_uint64(0), 0, 1, acc.ctypes.data_as(C.c_void_p), 7, None, None) == -1
+    assert b"reduce" in L.ptx_last_error()
+    assert L.ptx_render_multi(none, 65, C.byref(ph), C.c_uint64(0), 0, 1, acc.ctypes.data_as(C.c_void_p), 0, None, None) == -5
+    n = C.c_int(-1)
+    assert L.ptx_device_count(C.byref(n)) == 0 and n.value >= 0
