@@ -248,6 +248,16 @@ int ptx_intersect_batch(ptx_scene* scene, const ptx_ray* rays, size_t n, ptx_hit
  * streams are.  Launches of one handle therefore never overlap; use one handle per stream to overlap them. */
 int ptx_intersect_batch_device(ptx_scene* scene, const ptx_ray* d_rays, size_t n, ptx_hit* d_hits,
                                void* stream);
+/* ptx_intersect_batch_device for callers that cannot allocate (HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same kernel and same results; the work
+ * cursor and the stack-spill area live in a file-scope device array of the library (17.0 MiB per GPU, held
+ * until the process ends) instead of scene-owned allocations, and the call creates no event and takes no
+ * timing stamp: it enqueues one 4-byte memset and one kernel on `stream`.  At most PTX_NOALLOC_MAX_RAYS rays
+ * per call (PTX_E_LIMIT beyond).  All handles on one GPU share that array: calls that overlap on one GPU
+ * (two streams, two handles, two threads) race - the caller orders them. */
+#define PTX_NOALLOC_MAX_RAYS (1u << 24)
+int ptx_intersect_batch_device_noalloc(ptx_scene* scene, const ptx_ray* d_rays, size_t n, ptx_hit* d_hits,
+                                       void* stream);
 /* Occlusion only: out[i] = 1 iff `intersect(ray, t_range).is_some()` — the only thing the integrator
  * asks of a shadow ray (tracing/src/pathtracer.rs:72-78).  Device buffers. */
 int ptx_occluded_batch_device(ptx_scene* scene, const ptx_ray* d_rays, size_t n, uint8_t* d_out,

@@ -382,6 +382,10 @@ class DeviceScene:
     def intersect_device(self, d_rays_ptr, n, d_hits_ptr, stream=None):
         _check(lib().ptx_intersect_batch_device(self._h, C.c_void_p(d_rays_ptr), C.c_size_t(n), C.c_void_p(d_hits_ptr), C.c_void_p(stream)))
 
+    def intersect_device_noalloc(self, d_rays_ptr, n, d_hits_ptr, stream=None):
+        """ptx_intersect_batch_device for callers that cannot allocate (library-static scratch, <= NOALLOC_MAX_RAYS)."""
+        _check(lib().ptx_intersect_batch_device_noalloc(self._h, C.c_void_p(d_rays_ptr), C.c_size_t(n), C.c_void_p(d_hits_ptr), C.c_void_p(stream)))
+
     def occluded_device(self, d_rays_ptr, n, d_out_ptr, stream=None):
         _check(lib().ptx_occluded_batch_device(self._h, C.c_void_p(d_rays_ptr), C.c_size_t(n), C.c_void_p(d_out_ptr), C.c_void_p(stream)))
 
@@ -480,6 +484,7 @@ class DeviceScene:
         return {"extend": dict(zip(keys, (int(x) for x in raw[:12]))), "shadow": dict(zip(keys, (int(x) for x in raw[12:])))}
 
 
+NOALLOC_MAX_RAYS = 1 << 24
 REDUCE_AUTO, REDUCE_RCCL, REDUCE_PEER = 0, 1, 2
 
 

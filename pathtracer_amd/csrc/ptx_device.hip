@@ -246,6 +246,15 @@ constexpr uint32_t DESC_MAX_PAYLOAD = 0x3FFFFFFDu;  // offsets and triangle indi
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// Scratch of ptx_intersect_batch_device_noalloc (include/ptx.h): the launch's work cursor (first 256 bytes) and
+// the spill levels of the traversal stacks of NOALLOC_GRID workgroups.  File-scope device memory: every GPU the
+// library runs on holds its own copy at its own address until the process ends.  Host code never uses the
+// array's name as an address: ptx_scene_create asks hipGetSymbolAddress once per device and keeps the pointer.
+constexpr int NOALLOC_GRID = 256;  // workgroups of the allocation-free launch (one per CU)
+constexpr size_t NOALLOC_SPILL_BYTES = (size_t)(PTX_MAX_DEPTH - LDS_DEPTH) * NOALLOC_GRID * TBLOCK * sizeof(uint2);
+constexpr size_t NOALLOC_SCRATCH_BYTES = 256 + NOALLOC_SPILL_BYTES;  // 17.0 MiB
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
 struct TravArgs {
     const uint4* nodes;        // inner nodes, device layout
     uint32_t top_n;            // nodes [0, top_n) are copied into LDS by every workgroup (<= TOP_NODES)
@@ -1115,6 +1124,7 @@ struct ptx_scene {
     // every call waits for the event its predecessor recorded, whatever streams the two were given.
     hipEvent_t ev_batch = nullptr;
     bool batch_pending = false;
+    unsigned char* noalloc_scratch = nullptr;  // this device's copy of `scratch` (hipGetSymbolAddress at create time)
     // ptx_render_multi (ptx_multi.hip): this shard's accumulation buffer, a landing buffer for a peer's, a stream
     DevBuf<float> multi_accum, multi_tmp;
     hipStream_t multi_stream = nullptr;
@@ -1579,6 +1589,19 @@ int ptx_scene_create(const ptx_scene_desc* d, uint32_t flags, ptx_scene** out) {
     HIP_TRY(sc->spill.ensure((size_t)(PTX_MAX_DEPTH - LDS_DEPTH) * sc->tgrid * TBLOCK));
     HIP_TRY(sc->batch_cursor.ensure(1));
     HIP_TRY(hipEventCreateWithFlags(&sc->ev_batch, hipEventDisableTiming));
+    {
+        // the scratch array of the allocation-free entry point: its address on THIS device (every GPU holds
+        // its own copy), looked up once per device with that device current
+        static std::mutex mu;
+        static unsigned char* per_device[64] = {nullptr};
+        std::lock_guard<std::mutex> lock(mu);
+        unsigned char* ptr = sc->device < 64 ? per_device[sc->device] : nullptr;
+        if (!ptr) {
+            HIP_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+            if (sc->device < 64) per_device[sc->device] = ptr;
+        }
+        sc->noalloc_scratch = ptr;
+    }
     if (flags & PTX_FLAG_CHECK_BRUTE) {
         HIP_TRY(sc->fails.ensure(ptx_scene::FAIL_CAP));
         HIP_TRY(sc->check_count.ensure(2));
@@ -1638,6 +1661,23 @@ int ptx_intersect_batch_device(ptx_scene* sc, const ptx_ray* d_rays, size_t n, p
     HIP_TRY(hipEventRecord(sc->ev_batch, (hipStream_t)stream));
     sc->batch_pending = true;
     return rc;
+}
+
+int ptx_intersect_batch_device_noalloc(ptx_scene* sc, const ptx_ray* d_rays, size_t n, ptx_hit* d_hits, void* stream) {
+    int rc = check_scene(sc, "ptx_intersect_batch_device_noalloc");
+    if (rc) return rc;
+    if (n == 0) return PTX_OK;
+    if (!d_rays || !d_hits) return fail(PTX_E_ARG, "ptx_intersect_batch_device_noalloc: null buffer");
+    if (n > PTX_NOALLOC_MAX_RAYS)
+        return fail(PTX_E_LIMIT, "ptx_intersect_batch_device_noalloc: more than PTX_NOALLOC_MAX_RAYS (2^24) rays in one call");
+    unsigned char* const ptr = sc->noalloc_scratch;  // never the array's name: that is a host-side stand-in
+    if (!ptr) return fail(PTX_E_HIP, "ptx_intersect_batch_device_noalloc: the scratch array has no address on this device");
+    // No allocation, no event, no timing bracket: a memset node and one kernel launch on the caller's stream.
+    sc->batch_extend_rays += n;
+    ++sc->extend_launches;
+    HIP_TRY(hipMemsetAsync(ptr, 0, sizeof(uint32_t), (hipStream_t)stream));  // the cursor must start at zero
+    return launch_traverse<false>(sc, d_rays, SegRange{}, (uint32_t)n, d_hits, nullptr, reinterpret_cast<uint32_t*>(ptr),
+                                  reinterpret_cast<uint2*>(ptr + 256), sc->totals.p + 2, (hipStream_t)stream, NOALLOC_GRID);
 }
 
 int ptx_occluded_batch_device(ptx_scene* sc, const ptx_ray* d_rays, size_t n, uint8_t* d_out, void* stream) {
