@@ -174,7 +174,9 @@ int ptx_kdtree_stats(const float* triangles, uint32_t n_triangles, const ptx_kdn
                      const uint32_t* leaf_indices, uint32_t n_leaf_indices, const ptx_sah_cost* sah, ptx_tree_stats* out);
 
 /* `KdNode::intersect` for ONE ray on the host, over the flattened tree — the scalar form of the accel
- * seam (kdtree/src/lib.rs:73-132), for callers that need an occasional query without a GPU round trip. */
+ * seam (kdtree/src/lib.rs:73-132), for callers that need an occasional query without a GPU round trip.  The
+ * tree is validated first (PTX_E_ARG when malformed); leaf_indices must cover every leaf range the tree names
+ * (the signature carries no length for it).  Only the triangles of the visited leaves are touched. */
 int ptx_kdtree_intersect_host(const float* triangles, uint32_t n_triangles, const ptx_kdnode* nodes,
                               uint32_t n_nodes, const uint32_t* leaf_indices, const ptx_ray* ray,
                               ptx_hit* hit);

@@ -9,6 +9,7 @@
 //   kdtree/src/event.rs:46-96   event order = (f32 total order of distance, kind)
 // Output layout: include/ptx.h `ptx_kdnode`.
 #include <algorithm>
+#include <exception>
 #include <thread>
 #include <cstdlib>
 #include <vector>
@@ -267,9 +268,24 @@ struct Builder {
         split(c, p, L, R);
         c = Cell();
         Builder left = child(), right = child();
-        std::thread worker([&] { left.grow_parallel(L, depth + 1, par_levels - 1); });
-        right.grow_parallel(R, depth + 1, par_levels - 1);
+        // an exception on either side (bad_alloc on a huge scene) must reach the C ABI as an error code: the
+        // worker hands its own over, and the caller's side never leaves a joinable thread behind
+        std::exception_ptr worker_error;
+        std::thread worker([&] {
+            try {
+                left.grow_parallel(L, depth + 1, par_levels - 1);
+            } catch (...) {
+                worker_error = std::current_exception();
+            }
+        });
+        try {
+            right.grow_parallel(R, depth + 1, par_levels - 1);
+        } catch (...) {
+            worker.join();
+            throw;
+        }
         worker.join();
+        if (worker_error) std::rethrow_exception(worker_error);
         const size_t me = nodes.size();
         uint32_t bits;
         std::memcpy(&bits, &p.d, 4);

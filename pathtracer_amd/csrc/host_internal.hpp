@@ -31,5 +31,6 @@ ptx_kdtree* kdtree_from_arrays(std::vector<ptx_kdnode>&& nodes, std::vector<uint
 //                                        f[7]=1/det(b1,b2), NaN when det == 0
 using TriRecord = TriRec;
 void pack_triangles(const float* tris, uint32_t n, std::vector<TriRecord>& out);
+void pack_triangle(const float* v0v1v2, TriRecord& out);
 
 }  // namespace ptx

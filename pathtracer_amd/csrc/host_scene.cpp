@@ -385,10 +385,26 @@ int ptx_kdtree_intersect_host(const float* triangles, uint32_t n_triangles, cons
                               uint32_t n_nodes, const uint32_t* leaf_indices, const ptx_ray* ray,
                               ptx_hit* hit) {
     if (!nodes || !ray || !hit || n_nodes == 0) return fail(PTX_E_ARG, "ptx_kdtree_intersect_host: null argument");
-    std::vector<TriRecord> recs;
-    pack_triangles(triangles, n_triangles, recs);
+    if (n_triangles && !triangles) return fail(PTX_E_ARG, "ptx_kdtree_intersect_host: triangles missing");
+    // The walk indexes with what the tree says: prove it sound first.  The ABI carries no length for the leaf
+    // index list, so the list must cover every leaf range the tree names (documented in ptx.h); what CAN be
+    // checked is - children, ranges below 2^30, depth, and every listed triangle index below n_triangles.
+    uint64_t need = 0;
+    for (uint32_t i = 0; i < n_nodes; ++i)
+        if ((nodes[i].w1 & 3u) == 3u) need = std::max<uint64_t>(need, (uint64_t)nodes[i].w0 + (nodes[i].w1 >> 2));
+    if (need >= (1ull << 30) || (need && !leaf_indices)) return fail(PTX_E_ARG, "ptx_kdtree_intersect_host: leaf ranges out of bounds");
+    const std::string why = validate_flat_tree(nodes, n_nodes, leaf_indices, (uint32_t)need, n_triangles);
+    if (!why.empty()) return fail(PTX_E_ARG, "ptx_kdtree_intersect_host: invalid flattened tree: " + why);
+    struct OnDemand {  // packs only the triangles of the leaves the ray visits
+        const float* t;
+        TriRecord operator[](uint32_t i) const {
+            TriRecord r;
+            pack_triangle(t + 9 * (size_t)i, r);
+            return r;
+        }
+    } tris{triangles};
     WorkCount wc{0, 0};
-    kd_traverse<false, false>(nodes, leaf_indices, recs.data(), ray->ox, ray->oy, ray->oz, ray->dx,
+    kd_traverse<false, false>(nodes, leaf_indices, tris, ray->ox, ray->oy, ray->oz, ray->dx,
                               ray->dy, ray->dz, ray->tmin, ray->tmax, *hit, wc);
     return PTX_OK;
 }
@@ -533,31 +549,31 @@ namespace ptx {
 
 void pack_triangles(const float* t, uint32_t n, std::vector<TriRecord>& out) {
     out.resize(n);
-    for (uint32_t i = 0; i < n; ++i) {
-        const float* v = t + 9 * (size_t)i;
-        TriRecord& r = out[i];
-        memset(&r, 0, sizeof r);
-        int axis = aligned_axis(v);
-        r.kind = (uint32_t)axis;
-        if (axis == 3) {
-            for (int c = 0; c < 3; ++c) {
-                r.f[c] = v[c];
-                r.f[3 + c] = v[3 + c] - v[c];
-                r.f[6 + c] = v[6 + c] - v[c];
-            }
-        } else {
-            const int a0 = axis == 0 ? 1 : 0;  // Axis::remove_from (axis.rs:27-33)
-            const int a1 = axis == 2 ? 1 : 2;
-            r.f[0] = v[axis];
-            r.f[1] = v[a0];
-            r.f[2] = v[a1];
-            r.f[3] = v[3 + a0] - v[a0];
-            r.f[4] = v[3 + a1] - v[a1];
-            r.f[5] = v[6 + a0] - v[a0];
-            r.f[6] = v[6 + a1] - v[a1];
-            const float det = r.f[3] * r.f[6] - r.f[5] * r.f[4];  // axial_triangle.rs:70
-            r.f[7] = det == 0.0f ? std::numeric_limits<float>::quiet_NaN() : 1.0f / det;
+    for (uint32_t i = 0; i < n; ++i) pack_triangle(t + 9 * (size_t)i, out[i]);
+}
+
+void pack_triangle(const float* v, TriRecord& r) {
+    memset(&r, 0, sizeof r);
+    int axis = aligned_axis(v);
+    r.kind = (uint32_t)axis;
+    if (axis == 3) {
+        for (int c = 0; c < 3; ++c) {
+            r.f[c] = v[c];
+            r.f[3 + c] = v[3 + c] - v[c];
+            r.f[6 + c] = v[6 + c] - v[c];
         }
+    } else {
+        const int a0 = axis == 0 ? 1 : 0;  // Axis::remove_from (axis.rs:27-33)
+        const int a1 = axis == 2 ? 1 : 2;
+        r.f[0] = v[axis];
+        r.f[1] = v[a0];
+        r.f[2] = v[a1];
+        r.f[3] = v[3 + a0] - v[a0];
+        r.f[4] = v[3 + a1] - v[a1];
+        r.f[5] = v[6 + a0] - v[a0];
+        r.f[6] = v[6 + a1] - v[a1];
+        const float det = r.f[3] * r.f[6] - r.f[5] * r.f[4];  // axial_triangle.rs:70
+        r.f[7] = det == 0.0f ? std::numeric_limits<float>::quiet_NaN() : 1.0f / det;
     }
 }
 

@@ -1,7 +1,7 @@
 // traverse.hpp — nearest-hit / any-hit traversal of the flattened KD-tree and the two triangle tests.
 //
-// One source for the gfx950 kernels (kernels.hip) and for the scalar host query
-// (ptx_kdtree_intersect_host), so both take the same decisions.  Semantics follow the reference:
+// tri_test() is shared by the gfx950 kernels (ptx_device.hip: k_traverse, k_check) and the host; kd_traverse()
+// is the scalar host query (ptx_kdtree_intersect_host) and the statement of the decisions k_traverse takes.  Semantics follow the reference:
 //   KdNode::intersect               kdtree/src/lib.rs:73-132
 //   intersect_closest_geometry      geometry/src/geometry.rs:176-196 (+ IndexedIntersection::min :47-53)
 //   Triangle::intersect_ray         geometry/src/triangle.rs:80-105   (Möller–Trumbore, two-sided)
@@ -95,9 +95,10 @@ struct WorkCount {
 
 // ANY = true: stop at the first accepted triangle (occlusion query; same yes/no as `.is_some()` on the
 // nearest-hit search, because both accept in the first leaf that holds a triangle inside its segment).
-template <bool ANY, bool COUNT>
+// `tris` is anything indexable by triangle number that yields a TriRec (an array, or a packer on demand).
+template <bool ANY, bool COUNT, class Tris>
 PTX_FN bool kd_traverse(const ptx_kdnode* __restrict__ nodes, const uint32_t* __restrict__ leaf_idx,
-                        const TriRec* __restrict__ tris, float ox, float oy, float oz, float dx,
+                        const Tris& tris, float ox, float oy, float oz, float dx,
                         float dy, float dz, float t_start, float t_end, ptx_hit& hit, WorkCount& wc) {
     uint32_t st_node[PTX_MAX_DEPTH];
     float st_t[PTX_MAX_DEPTH];

@@ -286,3 +286,16 @@ def test_render_multi_rejects_bad_arguments_before_touching_a_gpu():
     assert L.ptx_render_multi(none, 65, C.byref(ph), C.c_uint64(0), 0, 1, acc.ctypes.data_as(C.c_void_p), 0, None, None) == -5
     n = C.c_int(-1)
     assert L.ptx_device_count(C.byref(n)) == 0 and n.value >= 0
+
+
+def test_host_traversal_rejects_a_malformed_tree():  # validated before the walk, like ptx_scene_create
+    tris = np.array([[[0, 0, 1], [1, 0, 1], [0, 1, 1]]], f32).reshape(-1, 9)
+    nodes, leaf = orc.flat_tree(N(2, 1.0, L(0), L()))
+    ok = pt.KdTree(tris, nodes, leaf)
+    assert ok.intersect_host([0, 0, 0], [0, 0, 2], (0.0, 1.0))["index"] == 0
+    bad = nodes.copy()
+    bad["w1"][0] = (50 << 2) | 2  # right child far outside the array
+    with pytest.raises(pt.PtxError):
+        pt.KdTree(tris, bad, leaf).intersect_host([0, 0, 0], [0, 0, 2], (0.0, 1.0))
+    with pytest.raises(pt.PtxError):  # a leaf that names a triangle the caller did not pass
+        pt.KdTree(tris, nodes, np.array([7], np.uint32)).intersect_host([0, 0, 0], [0, 0, 2], (0.0, 1.0))
