@@ -28,10 +28,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
-# HBM bytes per extend ray of the default workload from the PMC passes of this round
-# (profiles/r01_v13_pmc_fetch_write.txt: k_traverse<nearest>, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 over the
-# rays of the profiled run; FETCH_SIZE doubled as MI355X_MICROARCH.md "HBM" prescribes for gfx950).
-MEASURED_EXTEND_HBM_BYTES_PER_RAY = {"cornell_teapot": 152.0}
+# HBM bytes per extend ray come from the committed summary of the PMC passes (profiles/hbm_traffic.json, written by
+# tools/pmc_summary.py --json from separate FETCH_SIZE / WRITE_SIZE runs of this bench; FETCH_SIZE doubled as
+# MI355X_MICROARCH.md "HBM" prescribes for gfx950), keyed by scene@size: a workload nobody profiled gets null.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+
+
+def measured_traffic(scene, size):
+    try:
+        with open(TRAFFIC_FILE) as f:
+            return json.load(f).get("%s@%s" % (scene, size.lower()))
+    except (OSError, ValueError):
+        return None
+
+
+class stdout_to_stderr:
+    """File descriptor 1 points at stderr inside the block: native libraries that print banners on stdout
+    cannot get between the driver and the ONE JSON line this script owes it."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
 
 
 def main():
@@ -48,6 +72,7 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--save", default="", help="write the tonemapped image (rank 0) to this PNG")
     ap.add_argument("--force-dist", action="store_true", help="run the torch.distributed path even with one rank (rehearsal)")
+    ap.add_argument("--no-config3", action="store_true", help="skip the extra one-call 1024-spp figure (BASELINE.json configs[2] literally)")
     args = ap.parse_args()
 
     import numpy as np
@@ -69,7 +94,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        with stdout_to_stderr():  # RCCL prints a version banner on stdout when its communicator comes up
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.all_reduce(torch.zeros(16, device="cuda"))
+            torch.cuda.synchronize()
 
     W, H = (int(x) for x in args.size.lower().split("x"))
     obj = os.path.join(ROOT, "scenes", args.scene + ".obj")
@@ -176,16 +204,24 @@ def main():
                 torch.cuda.synchronize()
                 ex = dev.stats()
                 ex_achieved = ex["extend_rays"] * b_ray / (ex["extend_ms"] * 1e-3) / 1e9
-            hbm_per_ray = MEASURED_EXTEND_HBM_BYTES_PER_RAY.get(args.scene) if (W, H) == (1080, 1080) else None
+            tr = measured_traffic(args.scene, args.size)
+            hbm_per_ray = tr["extend_bytes_per_ray"] if tr else None
+            rays_per_s = st["extend_rays"] / (ext_ms * 1e-3)
             out["roofline"] = {
                 "kernel": "k_traverse<nearest> (extend)",
+                # priced against HBM as SURVEY 8d defines it (algorithmic = cache-level bytes); what the counters
+                # name as the limiter is in "limited_by", and the HBM the kernel really moves in "hbm_measured"
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": hbm_per_ray * st["extend_rays"] / max(launches, 1) if hbm_per_ray else None,
-                "traffic_note": "HBM bytes per launch = PMC bytes per ray (profiles/, separate --pmc passes) x rays per launch",
+                "traffic_note": ("HBM bytes per launch = PMC bytes per ray (%s) x rays per launch" % tr["source"]) if tr
+                                else "no PMC summary committed for this scene@size (profiles/hbm_traffic.json)",
+                "limited_by": (tr or {}).get("limited_by", "VALU issue under divergence + dependent-load latency (see DESIGN.md 5); not HBM"),
+                "hbm_measured": {"bytes_per_ray": hbm_per_ray, "GBps": hbm_per_ray * rays_per_s / 1e9,
+                                 "frac": hbm_per_ray * rays_per_s / 1e9 / HBM_PEAK_GBS} if hbm_per_ray else None,
                 "bytes_per_ray": b_ray,
                 "inner_nodes_per_ray": nodes_per_ray,
                 "tri_tests_per_ray": tris_per_ray,
@@ -200,6 +236,23 @@ def main():
                     "extend_mrays_per_s": ex["extend_rays"] / ex["extend_ms"] / 1e3,
                     "avg_launch_ms": ex["extend_ms"] / max(ex["extend_launches"], 1),
                     "sample": "one batch of %d spp alone on the GPU (ptx_set_pipelines(1)), outside the timed region" % min(spp, 64)}
+        if world == 1 and not args.no_config3 and not args.batch_samples:
+            # BASELINE.json configs[2] literally: ONE ptx_render_device call of 1024 spp (the library cuts it into
+            # batches by itself), outside the timed region above
+            tmp = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
+            dev.stats_reset()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            dev.render_device(pinhole, 1024, tmp.data_ptr(), seed=0, first_sample=0, stream=stream)
+            torch.cuda.synchronize()
+            secs = time.perf_counter() - t1
+            c3 = dev.stats()
+            out["config3_1024spp"] = {
+                "workload": "%s.obj %s, one ptx_render_device call of 1024 spp" % (args.scene, args.size),
+                "samples_per_s": 1024.0 * W * H / secs, "seconds": secs,
+                "extend_mrays_per_s": c3["extend_rays"] / c3["extend_ms"] / 1e3 if c3["extend_ms"] > 0 else None,
+                "extend_launches": c3["extend_launches"]}
+            del tmp
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(obj, W, H, args.max_bounces)
         if args.save:

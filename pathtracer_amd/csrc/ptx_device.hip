@@ -1794,6 +1794,10 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
     // bytes per queue slot (see ensure_render_state) + the radiance of up to two paths per slot
     const uint64_t slot_bytes = 129 + (uint64_t)(L ? L : 1u) * (33 + (L > 1 ? 16 : 0)) + 24;
     uint64_t slot_budget = (sc->slot_budget ? sc->slot_budget : auto_queue_bytes(sc) / slot_bytes) / n_pipes;
+    // The automatic budget follows the free memory, which moves a little from call to call; queues that already
+    // cover three quarters of it are kept as they are rather than rebuilt 1 % wider (a rebuild stalls the call:
+    // device synchronisation plus ~150 GB of hipFree / hipMalloc)
+    if (!sc->slot_budget && sc->pipes.size() == n_pipes && sc->cap_slots >= slot_budget - slot_budget / 4) slot_budget = sc->cap_slots;
     const uint64_t max_batch_paths = (1ull << 31) - (1ull << 20);
     uint32_t S = 1, n_seg = 1, seg_range = 1, seg_cap = 64, rounds = 0;
     uint32_t want_S = sc->batch_samples;  // samples per batch, 0 = choose

@@ -1,4 +1,5 @@
-"""GPU parity at BASELINE.json's full sizes (-m gpu): cornell_teapot, 1080 x 1080.
+"""GPU parity at BASELINE.json's full sizes (-m gpu): cornell_teapot and cornell_textured at 1080 x 1080
+(configs[2], configs[3]), sr2 and cubesplosion at 3840 x 2160 (configs[4]).
 
 The oracle still finishes in seconds here when it is asked for one sample per pixel or a few million rays, so
 the full-size checks are direct comparisons; on top come the size-independent properties the renderer
@@ -91,4 +92,90 @@ def test_large_synthetic_tree_bit_exact():
     dev.occluded_device(d_rays.data_ptr(), len(rays), d_out.data_ptr())
     torch.cuda.synchronize()
     assert np.array_equal(d_out.cpu().numpy().astype(bool), want["index"] != 0xFFFFFFFF)
+    dev.close()
+
+
+def _render_dev(dev, ph, first, count, seed, stream):
+    import torch
+
+    buf = torch.zeros(ph.height * ph.width * 3, dtype=torch.float32, device="cuda")
+    dev.render_device(ph, count, buf.data_ptr(), seed=seed, first_sample=first, stream=stream)
+    torch.cuda.synchronize()
+    return buf
+
+
+def test_config4_cornell_textured_full_frame_bit_exact():
+    """configs[3] (texture lookups, refraction with total internal reflection, the metal box) at its full
+    1080 x 1080: 4 samples of every pixel against the oracle (4 threads x 1 iteration = the same left fold of
+    one-sample buffers), then the batching / sharding invariants at that size."""
+    import torch
+
+    path = os.path.join(ROOT, "scenes", "cornell_textured.obj")
+    ref = orc.Scene(path, max_bounces=10)
+    want, _ = ref.render(W, H, threads=4, iterations_per_thread=1, mode=1, seed=17, first_sample=3)
+    scene = pt.LoadedScene(path, max_bounces=10)
+    dev = scene.upload()
+    ph = scene.pinhole(W, H)
+    stream = torch.cuda.current_stream().cuda_stream
+    got = _render_dev(dev, ph, 3, 4, 17, stream)
+    assert got.cpu().numpy().tobytes() == want.tobytes()
+    # 2048 spp sharded 1024 / 512 / 256 per GPU (configs[3]) is this at scale: the shards of [0, 24) over 1, 2, 4
+    # and 8 "GPUs", each rendered on its own and summed in shard order, equal ptx_render_multi's peer fold
+    whole = _render_dev(dev, ph, 0, 24, 17, stream)
+    for n in (2, 8):
+        acc = None
+        for g in range(n):
+            first, count = pt.shard_samples(0, 24, n, g)
+            part = _render_dev(dev, ph, first, count, 17, stream)
+            acc = part if acc is None else acc + part
+        assert torch.allclose(acc, whole, rtol=2e-6, atol=1e-6)  # same samples, another order of the float sums
+    img = whole.cpu().numpy().reshape(H, W, 3) / 24
+    assert np.isfinite(img).all() and img.min() >= 0.0
+    dev.close()
+
+
+@pytest.mark.parametrize("name", ["sr2", "cubesplosion"])
+def test_config5_4k_frames_bit_exact_and_invariants(name):
+    """configs[4]: 3840 x 2160 (non-square camera, camera.rs:72; 8.3 M pixels; 4 resp. 2 lights).  16 samples of
+    every pixel bit-exact against the oracle (16 threads x 1 iteration), then at that size: a call split into
+    ranges, batches and pipelines, and path regeneration over a queue far smaller than the batch, change no bit."""
+    import torch
+
+    w, h = 3840, 2160
+    path = os.path.join(ROOT, "scenes", name + ".obj")
+    ref = orc.Scene(path, max_bounces=10)
+    want, _ = ref.render(w, h, threads=16, iterations_per_thread=1, mode=1, seed=23, first_sample=5)
+    scene = pt.LoadedScene(path, max_bounces=10)
+    dev = scene.upload()
+    ph = scene.pinhole(w, h)
+    stream = torch.cuda.current_stream().cuda_stream
+    got = _render_dev(dev, ph, 5, 16, 23, stream)
+    g = got.cpu().numpy()
+    assert g.tobytes() == want.tobytes()
+    assert (g.reshape(h, w, 3).sum(2) > 0).mean() > 0.05  # the picture is not empty
+    del want
+    # ranges + batches + pipelines
+    parts = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
+    dev.set_batch_samples(3)
+    dev.set_pipelines(2)
+    for first, count in ((5, 7), (12, 1), (13, 8)):
+        dev.render_device(ph, count, parts.data_ptr(), seed=23, first_sample=first, stream=stream)
+    torch.cuda.synchronize()
+    assert torch.equal(parts, got)
+    # path regeneration: 16 x 8.3 M = 133 M paths through 6 Mi queue slots
+    dev.set_pipelines(1)
+    dev.set_batch_samples(0)
+    dev.set_queue_slots(6 << 20)
+    regen = _render_dev(dev, ph, 5, 16, 23, stream)
+    assert torch.equal(regen, got)
+    ext, _ = dev.last_batch_counts()
+    assert len(ext) > 10  # more rounds than bounces: the segments were topped up with fresh camera rays
+    # a wide call with the default budget: 96 samples = 0.8 G paths, more than one batch may hold (2^31 - 2^20 ids)
+    dev.set_queue_slots(0)
+    a = _render_dev(dev, ph, 0, 96, 23, stream)
+    dev.set_batch_samples(32)
+    b = _render_dev(dev, ph, 0, 96, 23, stream)
+    assert torch.equal(a, b)
+    st = dev.stats()
+    assert st["samples"] == (16 + 16 + 16 + 96 + 96) * w * h
     dev.close()

@@ -40,11 +40,28 @@ def test_counter_sampler_matches_sequential_sampler_statistically(name, w, h, sp
     check(counter / spp, seq_a / spp, seq_b / spp, w * h)
 
 
+def measure(counter, seq_a, seq_b, n_pixels):
+    """The numbers behind check(): RMSE of the pair of reseeded CPU renders, of the GPU image against each,
+    and the per-channel bias in standard errors."""
+    base = rmse(seq_a, seq_b)
+    se = base / np.sqrt(n_pixels)
+    both = (seq_a.astype(np.float64) + seq_b.astype(np.float64)) / 2
+    bias = [abs(counter[..., c].mean(dtype=np.float64) - both[..., c].mean()) / se for c in range(3)]
+    return {"rmse_cpu_a_vs_cpu_b": base, "rmse_gpu_vs_cpu_a": rmse(counter, seq_a), "rmse_gpu_vs_cpu_b": rmse(counter, seq_b),
+            "bias_in_standard_errors": bias}
+
+
 @pytest.mark.gpu
-def test_gpu_image_within_tolerance_of_the_sequential_cpu_render():
+@pytest.mark.parametrize("name,w,h,spp", [("cornell_textured", 128, 128, 128), ("cornell_teapot", 128, 128, 128), ("sr2", 192, 108, 128)])
+def test_gpu_image_within_tolerance_of_the_sequential_cpu_render(name, w, h, spp):
+    """north_star's second correctness leg on the GPU: the HIP render against the reference-structured CPU
+    render (sequential per-thread streams, libm trig) at equal samples per pixel, three scenes (texture +
+    refraction, the headline scene, 4 lights + non-square camera).  The measured numbers are written to
+    gpurun_out/rmse_leg.json when that directory exists (they are quoted in DESIGN.md 6)."""
+    import json
+
     import pathtracer_amd as pt
 
-    name, w, h, spp = "cornell_textured", 96, 96, 128
     path = os.path.join(SCENES, name + ".obj")
     ref = orc.Scene(path)
     seq_a, _ = ref.render(w, h, threads=16, iterations_per_thread=spp // 16, mode=0, seed=1100)
@@ -53,6 +70,11 @@ def test_gpu_image_within_tolerance_of_the_sequential_cpu_render():
     dev = scene.upload()
     gpu = dev.render(scene.pinhole(w, h), spp, seed=13)
     dev.close()
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        rec = {"scene": name, "size": "%dx%d" % (w, h), "spp": spp, **measure(gpu / spp, seq_a / spp, seq_b / spp, w * h)}
+        with open(os.path.join(out_dir, "rmse_leg.json"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
     check(gpu / spp, seq_a / spp, seq_b / spp, w * h)
     # and the 8-bit picture: almost every pixel within a few codes of the CPU one at this sample count is
     # not a meaningful bar (noise); the bias bar above is.  What must hold exactly is the tone map itself:
