@@ -102,6 +102,7 @@ struct RenderState {
     uint64_t seed;
     uint32_t n_pixels, n_samples, first_sample;  // n_pixels = pixels of the rendered region
     uint32_t reg_x, reg_y, reg_w;                // the region's corner and width inside the cam.width x cam.height image
+    uint32_t tiles_per_row;                      // reg_w / 8 when local pixel numbers run over 8 x 8 tiles, else 0 (see image_pixel)
 };
 
 // ------------------------------------------------------------------------------------------ helpers
@@ -237,6 +238,24 @@ constexpr uint32_t REFILL_IDLE = PTX_REFILL_IDLE;
 constexpr uint32_t TRI_BATCH_NEAREST = PTX_TRI_BATCH;  // lanes that must wait in a leaf before the triangle step runs
 constexpr uint32_t TRI_BATCH_ANYHIT = PTX_TRI_BATCH_ANY;
 
+#ifndef PTX_NODE_UNROLL
+#define PTX_NODE_UNROLL 2  // node steps per loop iteration (1 / 2 / 3 / 4: 1.64 / 1.70 / 1.68 / 1.64 G samples/s)
+#endif
+#ifndef PTX_TRI_UNROLL
+#define PTX_TRI_UNROLL 2  // triangles per triangle step (1 / 2 / 3: 1.705 / 1.725 / 1.67 G samples/s)
+#endif
+#ifndef PTX_SHADE_WAVES
+#define PTX_SHADE_WAVES 1  // minimum waves per SIMD the register allocation of k_shade must allow
+#endif
+#ifndef PTX_ROUNDS
+#define PTX_ROUNDS 2  // (node steps, exit step) rounds per loop iteration before the triangle step is considered
+#endif
+#ifndef PTX_FORCE_LOBE
+#define PTX_FORCE_LOBE 0
+#endif
+#ifndef PTX_PIXEL_TILES
+#define PTX_PIXEL_TILES 1
+#endif
 #ifndef PTX_AUTO_MEMORY_FRACTION
 #define PTX_AUTO_MEMORY_FRACTION 0.5
 #endif
@@ -277,6 +296,27 @@ struct TravArgs {
     unsigned long long* prof;  // [12] loop profile (COUNT): see ptx_debug_loop_profile
 };
 
+// Leaving a leaf (kdtree/src/lib.rs:95-103).  The pop is read unconditionally (LDS offsets clamped into the column; for
+// an empty stack the "top" is the sentinel and the values go unused) and selected afterwards; the spill area is a rare
+// branch on top.  A finished lane keeps its answer in registers until the next refill writes it out.
+#define PTX_EXIT_STEP \
+            if (COUNT && __any(cur == DESC_EXIT)) pf_end_iter += lane == 0 ? 1u : 0u; \
+            if (cur == DESC_EXIT) { \
+                if (COUNT) ++pf_end; \
+                const uint32_t st = so - LVL; \
+                const uint32_t sb = st - LVL; \
+                uint2 top = PTX_SLOT(st < so_last ? st : so_last); \
+                uint32_t tb = PTX_SLOT(sb < so_last ? sb : so_last).y; \
+                if (st > so_last) { \
+                    top = PTX_SPILL(st); \
+                    if (sb > so_last) tb = PTX_SPILL(sb).y; \
+                } \
+                const bool done = bi != PTX_MISS || t2 == t_end || st == so0; \
+                cur = done ? DESC_IDLE : (int32_t)top.x; \
+                t1 = done ? t1 : u2f(top.y); \
+                t2 = done ? t2 : u2f(tb); \
+                so = done ? so : st; \
+            }
 template <bool ANY, bool COUNT>
 __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
     // Level 0 of a lane's stack column is a sentinel {-, t_end}: the entry "below" the first real entry, so a
@@ -397,6 +437,11 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
         // ---- step the live lanes until enough of them have finished to make a refill worthwhile
         for (;;) {
             if (COUNT) pf_iter += lane == 0 ? 1u : 0u, pf_walk += cur >= 0 ? 1u : 0u, pf_live += cur != DESC_IDLE ? 1u : 0u;
+#pragma unroll
+            for (int round = 0; round < PTX_ROUNDS; ++round) {
+            if (round > 0) { PTX_EXIT_STEP }  // (the last round's exit step comes after the triangle step)
+#pragma unroll
+            for (int node_sub = 0; node_sub < PTX_NODE_UNROLL; ++node_sub)
             if (cur >= 0) {  // node visit, kdtree/src/lib.rs:105-129
                 uint4 nd;  // the top of the tree comes from LDS: no L1 tag lookup, a fifth of the latency
                 if (cur < top_n) {
@@ -431,11 +476,14 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                 }
                 cur = (int32_t)next;
             }
+            }
             PTX_CLOCK(ck_node)
             const unsigned long long in_leaf = __ballot(cur < -2);
             const unsigned long long can_walk = __ballot(cur >= 0);
             if (in_leaf && ((uint32_t)__popcll(in_leaf) >= (ANY ? TRI_BATCH_ANYHIT : TRI_BATCH_NEAREST) || !can_walk)) {
                 if (COUNT) pf_tri_iter += lane == 0 ? 1u : 0u;
+#pragma unroll
+                for (int tri_sub = 0; tri_sub < PTX_TRI_UNROLL; ++tri_sub)
                 if (cur < -2) {  // one triangle of the leaf: geometry/src/geometry.rs:176-196
                     if (COUNT) ++pf_tri, ++n_tris;
                     TriRec rec;  // the whole 48-byte record in one go; the kind is its last word
@@ -461,26 +509,7 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                 }
             }
             PTX_CLOCK(ck_tri)
-            if (COUNT && __any(cur == DESC_EXIT)) pf_end_iter += lane == 0 ? 1u : 0u;
-            if (cur == DESC_EXIT) {  // leaving a leaf: kdtree/src/lib.rs:95-103
-                if (COUNT) ++pf_end;
-                // The pop is read unconditionally (LDS offsets clamped into the column; for an empty stack
-                // the "top" is the sentinel and the values go unused) and selected afterwards.
-                const uint32_t st = so - LVL;  // top entry, or the sentinel when the stack is empty
-                const uint32_t sb = st - LVL;  // the entry below it (wraps when st is the sentinel: clamped)
-                uint2 top = PTX_SLOT(st < so_last ? st : so_last);
-                uint32_t tb = PTX_SLOT(sb < so_last ? sb : so_last).y;
-                if (st > so_last) {  // rare: the top (and maybe the entry below) lives in the spill area
-                    top = PTX_SPILL(st);
-                    if (sb > so_last) tb = PTX_SPILL(sb).y;
-                }
-                // a finished lane keeps its answer in registers until the next refill writes it out (see above)
-                const bool done = bi != PTX_MISS || t2 == t_end || st == so0;
-                cur = done ? DESC_IDLE : (int32_t)top.x;
-                t1 = done ? t1 : u2f(top.y);
-                t2 = done ? t2 : u2f(tb);
-                so = done ? so : st;
-            }
+            PTX_EXIT_STEP
             PTX_CLOCK(ck_exit)
             const uint32_t live = (uint32_t)__popcll(__ballot(cur != DESC_IDLE));
             if (live == 0) break;
@@ -490,6 +519,7 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
 #undef PTX_CLOCK
 #undef PTX_SLOT
 #undef PTX_SPILL
+#undef PTX_EXIT_STEP
     if (COUNT) {
         wave_add(&a.work[0], n_inner);
         wave_add(&a.work[1], n_tris);
@@ -508,8 +538,17 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
     }
 }
 
-// Image pixel (row-major index into the full image) of the region's local pixel number.
+// Image pixel (row-major index into the full image) of the region's local pixel number.  Local numbers run over
+// 8 x 8 pixel tiles when the region is a whole number of tiles (tiles_per_row > 0), else along the rows: 64
+// consecutive path ids - one wave of camera rays, and what survives of it in the compacted queues of the later
+// bounces - then cover a square patch of the image instead of a 64 x 1 strip, so their rays share more of the
+// tree.  A pixel's samples do not depend on its number (the sampler is keyed by the image pixel).
 __device__ inline uint32_t image_pixel(const RenderState& st, uint32_t local) {
+    if (st.tiles_per_row) {
+        const uint32_t tile = local >> 6, in = local & 63u;
+        const uint32_t ty = tile / st.tiles_per_row, tx = tile - ty * st.tiles_per_row;
+        return (st.reg_y + ty * 8u + (in >> 3)) * st.cam.width + st.reg_x + tx * 8u + (in & 7u);
+    }
     return (st.reg_y + local / st.reg_w) * st.cam.width + st.reg_x + local % st.reg_w;
 }
 
@@ -599,7 +638,11 @@ __device__ inline Bsdf material_sample(const DevMaterial& m, V3 wi, V3 n, float 
     const float p_specular = specular_strength / total;
     const float p_diffuse = diffuse_strength / total;
     const float p_refraction = refraction_strength / total;
+#if PTX_FORCE_LOBE  // probe builds only (tools/lobe_probe.sh): every path takes one lobe, so k_shade runs without lobe divergence
+    const float r = PTX_FORCE_LOBE == 1 ? 0.0f : (PTX_FORCE_LOBE == 2 ? p_specular : 2.0f);
+#else
     const float r = ptx_u01(key, dim);
+#endif
     if (p_specular > 0.0f && r < p_specular) return sample_specular(wi, n, f, p_specular);
     if (r < p_specular + p_refraction) {
         // sample_refraction(surface, ior, f, td, p_refraction), material.rs:84-112
@@ -658,7 +701,7 @@ __device__ inline Bsdf material_sample(const DevMaterial& m, V3 wi, V3 n, float 
 
 // One bounce of trace_ray (pathtracer.rs:33-108) for every entry of the current extend queue.
 template <int NL /* compile-time light count, 0 = read it from the scene */>
-__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderState st, uint32_t round /* 1-based */) {
+__global__ __launch_bounds__(BLOCK, PTX_SHADE_WAVES) void k_shade(DevScene sc, RenderState st, uint32_t round /* 1-based */) {
     __shared__ uint32_t lds[4 * WAVES];
     const uint32_t q = (round - 1u) & 1u;
     const ptx_ray* __restrict__ rays_in = st.rays[q];
@@ -1826,15 +1869,15 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         n_seg = (uint32_t)sc->shade_grid;
         if ((batch_paths + 255) / 256 < n_seg) n_seg = (uint32_t)((batch_paths + 255) / 256);
         if (n_seg < 1) n_seg = 1;
-        seg_range = (uint32_t)((batch_paths + n_seg - 1) / n_seg);
-        seg_cap = (uint32_t)((seg_range + 63) / 64 * 64);
+        seg_range = (uint32_t)(((batch_paths + n_seg - 1) / n_seg + 63) / 64 * 64);  // whole waves / pixel tiles per segment
+        seg_cap = seg_range;
         if (slot_budget < (uint64_t)n_seg * seg_cap) {
             // the budget bounds the slots: fewer segments when it is under 64 slots per segment, then
             // narrower segments (path regeneration covers the rest of each segment's range)
             if (slot_budget / n_seg < 64) {
                 n_seg = (uint32_t)(slot_budget / 64 > 0 ? slot_budget / 64 : 1);
-                seg_range = (uint32_t)((batch_paths + n_seg - 1) / n_seg);
-                seg_cap = (uint32_t)((seg_range + 63) / 64 * 64);
+                seg_range = (uint32_t)(((batch_paths + n_seg - 1) / n_seg + 63) / 64 * 64);
+                seg_cap = seg_range;
             }
             const uint64_t by_budget = slot_budget / n_seg / 64 * 64;
             if (by_budget < seg_cap) seg_cap = (uint32_t)(by_budget >= 64 ? by_budget : 64);
@@ -1896,6 +1939,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         st.seed = seed;
         st.n_pixels = n_pixels;
         st.reg_x = reg.x, st.reg_y = reg.y, st.reg_w = reg.w;
+        st.tiles_per_row = (PTX_PIXEL_TILES && reg.w % 8u == 0 && reg.h % 8u == 0) ? reg.w / 8u : 0u;
         st.n_samples = ns;
         st.n_paths = ns * n_pixels;
         st.first_sample = first_sample + done;
