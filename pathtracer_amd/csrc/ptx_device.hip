@@ -566,7 +566,7 @@ __device__ inline void start_path(const RenderState& st, ptx_ray* __restrict__ r
     const float dz = st.cam.plane[2] + u * st.cam.dx[2] + v * st.cam.dy[2];
     reinterpret_cast<float4*>(rays)[2 * (size_t)slot] = make_float4(st.cam.position[0], st.cam.position[1], st.cam.position[2], u2f(pid));
     reinterpret_cast<float4*>(rays)[2 * (size_t)slot + 1] = make_float4(dx, dy, dz, u2f(1u));
-    trans[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    (void)trans;  // a path starts with transport (1, 1, 1): k_shade knows that from the bounce number, nothing is stored
     st.radiance[pid] = Rad{0.0f, 0.0f, 0.0f};
 }
 
@@ -732,8 +732,12 @@ __global__ __launch_bounds__(BLOCK, PTX_SHADE_WAVES) void k_shade(DevScene sc, R
             bounce = f2u(rb.w);  // 1-based: the bounce this ray has just traced
             const uint32_t base = ptx_dim_base(bounce, n_lights);
             const uint4 hraw = reinterpret_cast<const uint4*>(st.hits)[i];
-            const float4 Traw = st.transq[q][i];
-            const V3 T = v3(Traw.x, Traw.y, Traw.z);
+            // accumulated_transport = Vec3::ONE at the first bounce (pathtracer.rs:31): not stored by start_path
+            V3 T = v3(1.0f, 1.0f, 1.0f);
+            if (bounce != 1u) {
+                const float4 Traw = st.transq[q][i];
+                T = v3(Traw.x, Traw.y, Traw.z);
+            }
             if (hraw.x == PTX_MISS) {
                 // return accumulated_radiance + accumulated_transport * environment (pathtracer.rs:44-46)
                 Rad R = st.radiance[pid];
