@@ -5,9 +5,10 @@ A step = one pass of the wavefront path tracer (generate â†’ [extend â†’ shade â
 accumulate) over one batch of `--spp-per-step` samples of every pixel of the workload; inputs (scene,
 accumulation buffer) are resident in HBM before the timed region.  Default workload = BASELINE.json
 configs[2]: cornell_teapot.obj, 1080x1080, 4 steps x 640 spp = 2560 spp per GPU, max_bounces 10 (one step = one
-batch of 640 samples of every pixel = 747 M paths in flight, ~133 GB of queues out of the 288 GB; wider batches
+batch of 640 samples of every pixel = 747 M paths in flight, ~130 GB of queues out of the 288 GB; wider batches
 amortise the long-ray tail of every launch and the small late bounces: 128 / 256 / 640 spp per batch =
-1.26 / 1.44 / 1.55 G samples/s; the library sizes its batches from the free device memory).
+1.26 / 1.44 / 1.55 G samples/s in round 1; the library sizes its batches from the free device memory).  The line also
+carries `config3_1024spp`: BASELINE.json configs[2] literally, one ptx_render_device call of 1024 spp.
 
 Multi-GPU: one process per GPU (torchrun), the scene replicated, every rank renders its own sample
 range (global sample index = rank * steps * spp + ...; counter-based sampler, so ranks never overlap),
