@@ -324,6 +324,12 @@ int ptx_set_queue_slots(ptx_scene* scene, uint64_t slots);
  * faster than two narrower overlapped ones); results do not depend on it.  No counterpart in the reference. */
 int ptx_set_pipelines(ptx_scene* scene, uint32_t pipelines);
 
+/* `ImageBuffer::to_rgb8` on the device (tracing/src/image_buffer.rs:29-38): d_accum (width*height*3
+ * floats) -> d_out (width*height*3 bytes), both on the current HIP device, asynchronous on `stream`.  Same rule as
+ * ptx_tonemap_rgb8 including the u16 truncation of `iterations`; the power is taken in f64 and rounded once, so a
+ * byte can differ from the host entry point's only where libm's powf is not correctly rounded. */
+int ptx_tonemap_rgb8_device(const float* d_accum, uint32_t width, uint32_t height, uint32_t iterations,
+                            uint8_t* d_out_rgb8, void* stream);
 /* Queue lengths of the most recent render batch: extend_counts[r] / shadow_counts[r] = entries of round r+1
  * (one round = extend + shade + shadow over everything in flight; without path regeneration round r is
  * bounce r; shadow counts are paths: multiply by the number of lights).  n = capacity of each array. */

@@ -530,6 +530,11 @@ def to_rgb8(accum, iterations):
     return out
 
 
+def to_rgb8_device(d_accum_ptr, width, height, iterations, d_out_ptr, stream=None):
+    """`ImageBuffer::to_rgb8` on the device: width*height*3 floats -> bytes, asynchronous on `stream`."""
+    _check(lib().ptx_tonemap_rgb8_device(C.c_void_p(d_accum_ptr), width, height, iterations, C.c_void_p(d_out_ptr), C.c_void_p(stream)))
+
+
 def write_png(path, rgb8):
     a = np.ascontiguousarray(rgb8, np.uint8)
     _check(lib().ptx_png_write_rgb8(os.fsencode(path), _ptr(a), a.shape[1], a.shape[0]))

@@ -12,7 +12,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <exception>
 #include <fstream>
+#include <iterator>
 #include <limits>
 #include <map>
 #include <memory>
@@ -128,24 +131,41 @@ bool corner(Cursor& c, Corner& out) {  // obj.rs:102-109: v/[t]/[n]
     return true;
 }
 
-void read_obj(std::istream& in, ObjFile& obj) {
+// One part of an OBJ file: what its lines add, in file order.  `head` holds the faces that come before the
+// part's first usemtl: they belong to the group that is open when the part starts.
+struct ObjPart {
+    std::string mtllib;
+    bool has_mtllib = false;
+    std::vector<float> v, vn, vt;
+    std::vector<std::vector<Corner>> head;
+    std::string head_line;  // first face line of `head` (for the "face before any usemtl" message)
+    std::vector<Group> groups;
+    std::string error;  // first malformed line of the part
+};
+
+void parse_obj_part(const char* p, const char* end, ObjPart& part) {
     std::string raw;
-    while (std::getline(in, raw)) {
+    while (p < end) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+        const char* stop = nl ? nl : end;
+        raw.assign(p, stop);
+        p = nl ? nl + 1 : end;
         std::string line = strip(raw);
         if (line.empty() || line[0] == '#') continue;
         Cursor c{line.c_str()};
         float f[3];
         // tag order of obj.rs:135-155; the tags are matched case-insensitively (tag_no_case)
         if (c = Cursor{line.c_str()}, c.keyword("mtllib", true)) {
-            obj.mtllib = c.p;
+            part.mtllib = c.p;
+            part.has_mtllib = true;
         } else if (c = Cursor{line.c_str()}, c.keyword("usemtl", true)) {
-            obj.groups.push_back(Group{c.p, {}});
+            part.groups.push_back(Group{c.p, {}});
         } else if (c = Cursor{line.c_str()}, c.keyword("v", true) && c.reals(f, 3)) {
-            obj.v.insert(obj.v.end(), f, f + 3);
+            part.v.insert(part.v.end(), f, f + 3);
         } else if (c = Cursor{line.c_str()}, c.keyword("vn", true) && c.reals(f, 3)) {
-            obj.vn.insert(obj.vn.end(), f, f + 3);
+            part.vn.insert(part.vn.end(), f, f + 3);
         } else if (c = Cursor{line.c_str()}, c.keyword("vt", true) && c.reals(f, 2)) {
-            obj.vt.insert(obj.vt.end(), f, f + 2);
+            part.vt.insert(part.vt.end(), f, f + 2);
         } else if (c = Cursor{line.c_str()}, c.keyword("f", true)) {
             std::vector<Corner> face;
             Corner k;
@@ -160,15 +180,71 @@ void read_obj(std::istream& in, ObjFile& obj) {
                     c = q;
                 }
             }
-            if (obj.groups.empty()) throw std::runtime_error("face before any usemtl: \"" + raw + "\"");
-            obj.groups.back().faces.push_back(face);
+            if (part.groups.empty()) {
+                if (part.head.empty()) part.head_line = raw;
+                part.head.push_back(face);
+            } else {
+                part.groups.back().faces.push_back(face);
+            }
         } else if ((c = Cursor{line.c_str()}, c.keyword("g", true)) ||
                    (c = Cursor{line.c_str()}, c.keyword("o", true)) ||
                    (c = Cursor{line.c_str()}, c.keyword("s", true))) {
             // ignored, as in the reference
         } else {
-            throw std::runtime_error("Unexpected line: \"" + raw + "\"");
+            part.error = "Unexpected line: \"" + raw + "\"";
+            return;  // the reference panics here (obj.rs:154): nothing after the line matters
         }
+    }
+}
+
+// `obj::obj` (wavefront/src/obj.rs:117-166).  Lines are independent except for "the group that is open", so the
+// file is cut at line ends into one part per thread (PTX_BUILD_THREADS, at most 16; small files stay on the calling
+// thread), the parts are parsed concurrently and spliced in file order: the result, and the first error, are those
+// of a sequential pass.
+void read_obj(std::istream& in, ObjFile& obj) {
+    std::string text((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    unsigned want = std::thread::hardware_concurrency();
+    if (want > 16) want = 16;
+    if (const char* e = getenv("PTX_BUILD_THREADS")) want = (unsigned)std::max(1, atoi(e));
+    if (want < 1 || text.size() < (1u << 18)) want = 1;
+    std::vector<size_t> cut{0};
+    for (unsigned k = 1; k < want; ++k) {
+        size_t at = text.size() * k / want;
+        const size_t nl = text.find('\n', at);
+        at = nl == std::string::npos ? text.size() : nl + 1;
+        if (at > cut.back() && at < text.size()) cut.push_back(at);
+    }
+    cut.push_back(text.size());
+    const size_t n_parts = cut.size() - 1;
+    std::vector<ObjPart> parts(n_parts);
+    std::vector<std::exception_ptr> thrown(n_parts);
+    auto work = [&](size_t k) {
+        try {
+            parse_obj_part(text.data() + cut[k], text.data() + cut[k + 1], parts[k]);
+        } catch (...) {
+            thrown[k] = std::current_exception();
+        }
+    };
+    {
+        std::vector<std::thread> pool;
+        for (size_t k = 1; k < n_parts; ++k) pool.emplace_back(work, k);
+        work(0);
+        for (auto& t : pool) t.join();
+    }
+    for (size_t k = 0; k < n_parts; ++k) {  // splice in file order; the first problem in file order wins
+        if (thrown[k]) std::rethrow_exception(thrown[k]);
+        ObjPart& part = parts[k];
+        if (part.has_mtllib) obj.mtllib = part.mtllib;
+        obj.v.insert(obj.v.end(), part.v.begin(), part.v.end());
+        obj.vn.insert(obj.vn.end(), part.vn.begin(), part.vn.end());
+        obj.vt.insert(obj.vt.end(), part.vt.begin(), part.vt.end());
+        if (!part.head.empty()) {
+            if (obj.groups.empty()) throw std::runtime_error("face before any usemtl: \"" + part.head_line + "\"");
+            auto& faces = obj.groups.back().faces;
+            faces.insert(faces.end(), std::make_move_iterator(part.head.begin()), std::make_move_iterator(part.head.end()));
+        }
+        for (auto& g : part.groups) obj.groups.push_back(std::move(g));
+        if (!part.error.empty()) throw std::runtime_error(part.error);
     }
 }
 

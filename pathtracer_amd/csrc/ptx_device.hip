@@ -1053,6 +1053,26 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(RenderState st, float* __r
     }
 }
 
+// `ImageBuffer::to_rgb8` (image_buffer.rs:29-38) on the device: gamma 1/2.2, clamp, round, saturate; NaN -> 0.  The
+// power is taken in f64 and rounded once to f32, which is what a correctly rounded powf gives (the host entry point
+// uses libm's powf): 4 channel values per lane, one dword store.
+__global__ __launch_bounds__(256) void k_tonemap(const float* __restrict__ accum, size_t n, float inv, uint8_t* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        uint32_t packed = 0;
+        const uint32_t m = n - i < 4 ? (uint32_t)(n - i) : 4u;
+        for (uint32_t k = 0; k < m; ++k) {
+            float g = (float)pow((double)(accum[i + k] * inv), (double)(1.0f / 2.2f));
+            g = g < 1.0f ? g : 1.0f;
+            const float c = roundf(g * 255.0f);
+            const uint32_t b = !(c == c) ? 0u : (c <= 0.0f ? 0u : (c >= 255.0f ? 255u : (uint32_t)c));
+            packed |= b << (8u * k);
+        }
+        if (m == 4 && (reinterpret_cast<uintptr_t>(out + i) & 3u) == 0) *reinterpret_cast<uint32_t*>(out + i) = packed;
+        else for (uint32_t k = 0; k < m; ++k) out[i + k] = (uint8_t)(packed >> (8u * k));
+    }
+}
+
 __global__ void k_tally(RenderState st, uint32_t rounds, uint32_t n_lights) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         unsigned long long e = 0, s = 0;
@@ -2100,6 +2120,20 @@ int ptx_render(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uint32_t fi
     HIP_TRY(hipDeviceSynchronize());
     sc->total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     HIP_TRY(hipMemcpy(accum_host, sc->stage_accum.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return PTX_OK;
+}
+
+int ptx_tonemap_rgb8_device(const float* d_accum, uint32_t width, uint32_t height, uint32_t iterations, uint8_t* d_out,
+                            void* stream) {
+    if (!d_accum || !d_out) return fail(PTX_E_ARG, "ptx_tonemap_rgb8_device: null argument");
+    const size_t n = (size_t)width * height * 3;
+    if (n == 0) return PTX_OK;
+    const uint16_t iters = (uint16_t)iterations;  // `total_iterations as u16` (worker.rs:113)
+    const float inv = 1.0f / (float)iters;
+    const size_t groups = (n + 3) / 4;
+    const int grid = (int)(groups / 256 + 1 < 4096 ? groups / 256 + 1 : 4096);
+    k_tonemap<<<grid, 256, 0, (hipStream_t)stream>>>(d_accum, n, inv, d_out);
+    HIP_TRY(hipGetLastError());
     return PTX_OK;
 }
 

@@ -235,3 +235,26 @@ def test_render_shrinks_its_queues_when_device_memory_is_short():
     assert got.tobytes() == want.tobytes()
     assert len(ext) > 5  # narrower queues: path regeneration ran more rounds than bounces
     dev.close()
+
+
+def test_device_tonemap_equals_the_host_tonemap():
+    """`to_rgb8` as a kernel.  Bytes equal the host entry point's (== the oracle's) on a rendered frame and
+    on the special values; a byte may differ by one code only where libm's powf is not correctly rounded."""
+    import torch
+
+    scene = pt.LoadedScene(os.path.join(SCENES, "cornell_textured.obj"), max_bounces=6)
+    dev = scene.upload()
+    w, h, spp = 250, 131, 24  # 3 * w * h is not a multiple of 4: the tail lanes store bytes
+    acc = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
+    dev.render_device(scene.pinhole(w, h), spp, acc.data_ptr(), seed=4)
+    acc[:12] = torch.tensor([0.0, -1.0, float("nan"), float("inf"), -float("inf"), 1e-30, spp * 1.0, spp * 0.999, spp * 1.001, 1e30, -0.0, spp * 0.5])
+    out = torch.full((h * w * 3,), 7, dtype=torch.uint8, device="cuda")
+    for iters in (spp, 65536 + spp):  # `as u16`: 65560 iterations tone-map like 24
+        pt.to_rgb8_device(acc.data_ptr(), w, h, iters, out.data_ptr())
+        torch.cuda.synchronize()
+        want = pt.to_rgb8(acc.cpu().numpy().reshape(h, w, 3), iters).reshape(-1).astype(np.int32)
+        got = out.cpu().numpy().astype(np.int32)
+        diff = np.abs(got - want)
+        assert diff.max() <= 1 and (diff != 0).mean() < 1e-5
+        assert list(got[:12]) == list(want[:12]) and got[0] == 0 and got[3] == 255  # zero, negative, NaN (`min` keeps the 1.0), inf, ...
+    dev.close()

@@ -299,3 +299,53 @@ def test_host_traversal_rejects_a_malformed_tree():  # validated befo
         pt.KdTree(tris, bad, leaf).intersect_host([0, 0, 0], [0, 0, 2], (0.0, 1.0))
     with pytest.raises(pt.PtxError):  # a leaf that names a triangle the caller did not pass
         pt.KdTree(tris, nodes, np.array([7], np.uint32)).intersect_host([0, 0, 0], [0, 0, 2], (0.0, 1.0))
+
+
+def test_parallel_obj_parse_equals_the_serial_pass(tmp_path):
+    """the OBJ file is cut at line ends and its parts parsed on several threads; arrays, group
+    boundaries and the first error are those of one sequential pass (PTX_BUILD_THREADS=1)."""
+    import hashlib
+    import subprocess
+    import sys
+
+    # a file large enough to be cut (> 256 KiB): 30 000 triangles in 3 groups, the usemtl lines far from the cuts' ends
+    rng = np.random.default_rng(3)
+    lines = ["mtllib big.mtl"]
+    n = 30000
+    for i in range(n):
+        if i % 10000 == 0:
+            lines.append("usemtl m%d" % (i // 10000))
+        p = rng.random((3, 3)).astype(f32) + i % 7
+        for v in p:
+            lines.append("v %.6f %.6f %.6f" % tuple(v))
+        lines.append("vn 0 0 1")
+        lines.append("f %d//%d %d//%d %d//%d" % (3 * i + 1, i + 1, 3 * i + 2, i + 1, 3 * i + 3, i + 1))
+    (tmp_path / "big.mtl").write_text("newmtl m0\nKd 0.5 0.5 0.5\nnewmtl m1\nKd 0.1 0.9 0.1\nnewmtl m2\nKd 0.9 0.1 0.1\n"
+                                      "newcamera c\ncameraposition 0 0 5\ncameratarget 0 0 0\ncameraup 0 1 0\ncamerafov 45\n")
+    obj = tmp_path / "big.obj"
+    obj.write_text("\n".join(lines) + "\n")
+    code = ("import sys, hashlib; sys.path.insert(0, %r); import pathtracer_amd as pt; a = pt.LoadedScene(%r).arrays(); "
+            "print(hashlib.sha256(a['triangles'].tobytes() + a['normals'].tobytes() + a['material_ids'].tobytes()).hexdigest(), len(a['triangles']), a['material_ids'][[0, 9999, 10000, 29999]].tolist())"
+            % (ROOT, str(obj)))
+    outs = {subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PTX_BUILD_THREADS=t), capture_output=True, text=True,
+                           check=True).stdout.strip() for t in ("1", "3", "16")}
+    assert len(outs) == 1
+    out = outs.pop()
+    assert out.endswith("30000 [0, 0, 1, 2]")
+    # errors: the FIRST bad line of the file is the one reported, wherever the cuts fall
+    bad = lines[:]
+    bad[len(bad) // 3] = "bogus first"
+    bad[2 * len(bad) // 3] = "bogus second"
+    obj.write_text("\n".join(bad) + "\n")
+    for t in ("1", "8"):
+        os.environ["PTX_BUILD_THREADS"] = t
+        try:
+            with pytest.raises(pt.PtxError) as e:
+                pt.LoadedScene(str(obj))
+        finally:
+            del os.environ["PTX_BUILD_THREADS"]
+        assert "bogus first" in str(e.value) and "second" not in str(e.value)
+    obj.write_text("\n".join(l for l in lines if not l.startswith("usemtl")) + "\n")  # faces, but no group ever opens
+    with pytest.raises(pt.PtxError) as e:
+        pt.LoadedScene(str(obj))
+    assert "usemtl" in str(e.value)
