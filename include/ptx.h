@@ -359,7 +359,8 @@ int ptx_raylog_enable(ptx_scene* scene, uint64_t max_records);
 int ptx_raylog_read(ptx_scene* scene, uint8_t* out, uint64_t cap_records, uint64_t* n_written, uint64_t* n_dropped);
 /* Diagnostic (scenes created with PTX_FLAG_COUNT_WORK; no counterpart in the reference): how the lanes of
  * the traversal kernels spent their loop iterations since the last reset.  out24[0..11] = extend,
- * out24[12..23] = shadow: wave iterations, lane-visits of the node step, wave iterations that ran the
+ * out24[12..23] = shadow: wave iterations (one iteration = 2 rounds of 2 node steps + a leaf-exit step, then
+ * up to 2 triangles per waiting lane), lane-visits of the node steps, wave iterations that ran the
  * triangle step, lane-visits of it, wave iterations that ran the leaf-exit step, lane-visits of it,
  * refill rounds, live lane-iterations, then the wave clock (s_memtime ticks, summed over waves) spent in the
  * refill, node, triangle and leaf-exit parts of the loop. */

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
 
         // ---- step the live lanes until enough of them have finished to make a refill worthwhile
         for (;;) {
-            if (COUNT) pf_iter += lane == 0 ? 1u : 0u, pf_walk += cur >= 0 ? 1u : 0u, pf_live += cur != DESC_IDLE ? 1u : 0u;
+            if (COUNT) pf_iter += lane == 0 ? 1u : 0u, pf_live += cur != DESC_IDLE ? 1u : 0u;
 #pragma unroll
             for (int round = 0; round < PTX_ROUNDS; ++round) {
             if (round > 0) { PTX_EXIT_STEP }  // (the last round's exit step comes after the triangle step)
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                 } else {
                     nd = a.nodes[cur];
                 }
-                if (COUNT) ++n_inner;
+                if (COUNT) ++n_inner, ++pf_walk;
                 const uint32_t axis = nd.y;
                 const float dist = u2f(nd.x);
                 const float da = pick(dx, dy, dz, axis);

@@ -247,15 +247,15 @@ int ptx_render_multi(ptx_scene* const* scenes, uint32_t n_scenes, const ptx_pinh
     if (how == PTX_REDUCE_AUTO) how = (distinct && n_scenes > 1) ? PTX_REDUCE_RCCL : PTX_REDUCE_PEER;
     if (how == PTX_REDUCE_RCCL && !distinct)
         return fail(PTX_E_ARG, "ptx_render_multi: RCCL needs every scene on a GPU of its own (use PTX_REDUCE_PEER)");
-    int before = 0;
-    HIP_TRY(hipGetDevice(&before));
+    struct DeviceGuard {  // whatever happens below, the caller's current device is what it was
+        int before = 0;
+        ~DeviceGuard() { (void)hipSetDevice(before); }
+    } guard;
+    HIP_TRY(hipGetDevice(&guard.before));
     for (uint32_t g = 0; g < n_scenes; ++g) {
         void* stream = nullptr;
         int rc = internal_multi_slot(sh[g].scene, n_floats, &sh[g].accum, g == 0 && how == PTX_REDUCE_PEER ? &sh[g].tmp : nullptr, &stream);
-        if (rc) {
-            (void)hipSetDevice(before);
-            return rc;
-        }
+        if (rc) return rc;
         sh[g].stream = (hipStream_t)stream;
         // shard 0 starts from the caller's buffer (`ImageBuffer` is added into, never cleared), the others from zero
         if (g == 0) HIP_TRY(hipMemcpyAsync(sh[g].accum, accum_host, n_floats * sizeof(float), hipMemcpyHostToDevice, sh[g].stream));
@@ -299,7 +299,6 @@ int ptx_render_multi(ptx_scene* const* scenes, uint32_t n_scenes, const ptx_pinh
         const hipError_t e2 = e1 == hipSuccess ? hipMemcpy(accum_host, sh[0].accum, n_floats * sizeof(float), hipMemcpyDeviceToHost) : e1;
         if (e2 != hipSuccess) rc = hip_fail(e2, "ptx_render_multi: reading the summed buffer back");
     }
-    (void)hipSetDevice(before);
     return rc;
 }
 

@@ -21,7 +21,7 @@ for k, rays, inner, tris in (("extend", st["extend_rays"], st["extend_inner_node
     it = max(p["iters"], 1)
     print("%s: rays %d  inner/ray %.2f  tris/ray %.2f  leaf-exits/ray %.2f" % (k, rays, inner / rays, tris / rays, p["end_lanes"] / rays))
     print("   wave iterations/ray*64 = %.1f  (node-step visits/ray %.2f)" % (it * 64 / rays, p["walk_lanes"] / rays))
-    print("   node step: lanes active %.1f/64   live lanes %.1f/64" % (p["walk_lanes"] / it, p["live_lanes"] / it))
+    print("   node steps: %.1f lane-visits per iteration (4 node steps: %.1f/64 lanes each)   live lanes at iteration start %.1f/64" % (p["walk_lanes"] / it, p["walk_lanes"] / it / 4, p["live_lanes"] / it))
     print("   tri step : ran in %.1f%% of iterations, lanes active %.1f/64" % (100 * p["tri_iters"] / it, p["tri_lanes"] / max(p["tri_iters"], 1)))
     print("   leaf exit: ran in %.1f%% of iterations, lanes active %.1f/64" % (100 * p["end_iters"] / it, p["end_lanes"] / max(p["end_iters"], 1)))
     print("   refill rounds per 100 iterations %.1f" % (100 * p["refills"] / it))
