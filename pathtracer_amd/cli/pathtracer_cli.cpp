@@ -32,6 +32,7 @@ struct Args {
     uint32_t gpus = 1;
     uint32_t reduce = PTX_REDUCE_AUTO;
     bool share_device = false;
+    bool multi = false;  // go through ptx_render_multi (implied by --gpus > 1; --reduce asks for it with one GPU too)
     std::string ray_log, checkpoint, resume;
     uint64_t ray_log_max = 1ull << 26;  // records held on the device per iteration
 };
@@ -116,6 +117,7 @@ int main(int argc, char** argv) {
         else if (k == "--gpus") a.gpus = (uint32_t)strtoul(val(), nullptr, 10);
         else if (k == "--share-device") a.share_device = true;
         else if (k == "--reduce") {
+            a.multi = true;
             const std::string r = val();
             if (r == "rccl") a.reduce = PTX_REDUCE_RCCL;
             else if (r == "peer") a.reduce = PTX_REDUCE_PEER;
@@ -132,7 +134,8 @@ int main(int argc, char** argv) {
     if (a.output.empty()) usage("the following required arguments were not provided: --output <OUTPUT>");
     if (a.max_bounces > 255) usage("max-bounces is a u8");
     if (a.gpus < 1 || a.gpus > 64) usage("--gpus takes 1..64");
-    if (a.gpus > 1 && !a.ray_log.empty()) usage("--ray-log writes one thread's file: use one GPU");
+    if (a.gpus > 1) a.multi = true;
+    if (a.multi && !a.ray_log.empty()) usage("--ray-log writes one thread's file: use one GPU and no --reduce");
 
     auto die = [](const char* what) {
         fprintf(stderr, "%s: %s\n", what, ptx_last_error());
@@ -163,7 +166,7 @@ int main(int argc, char** argv) {
 
     const uint32_t total = a.threads * a.iterations_per_thread;
     printf("Rendering %ux%u px image with %u thread(s) and %u total iteration(s)...\n", a.width, a.height, a.threads, total);
-    if (a.gpus > 1) printf("Sharding the iterations over %u GPU(s)%s\n", a.gpus, a.share_device ? " (all on one device)" : "");
+    if (a.multi) printf("Sharding the iterations over %u GPU(s)%s\n", a.gpus, a.share_device ? " (all on one device)" : "");
     std::vector<float> accum((size_t)a.width * a.height * 3, 0.0f);
     uint32_t first = 0;  // samples already in the buffer
     if (!a.resume.empty()) {
@@ -173,7 +176,7 @@ int main(int argc, char** argv) {
     }
     Progress prog{a.threads, total};
     auto t0 = std::chrono::steady_clock::now();
-    if (a.gpus > 1) {
+    if (a.multi) {
         if (ptx_render_multi(scenes.data(), a.gpus, &pinhole, a.seed, first, total, accum.data(), a.reduce, on_progress, &prog)) die("render");
     } else if (a.ray_log.empty()) {
         if (ptx_render(scene, &pinhole, a.seed, first, total, accum.data(), on_progress, &prog)) die("render");
@@ -199,7 +202,7 @@ int main(int argc, char** argv) {
     }
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     printf("\nTotal time: %.2fs\n", secs);
-    if (a.gpus > 1) {
+    if (a.multi) {
         double ms = 0;
         ptx_multi_last_reduce_ms(&ms);
         printf("Reduce over %u GPU(s): %.2f ms\n", a.gpus, ms);

@@ -79,6 +79,13 @@ def test_cli_gpus_flag_shards_and_matches_the_library(tmp_path):
     assert open(out, "rb").read() == open(ref, "rb").read()
     for d in devs:
         d.close()
+    # one GPU through the RCCL path in a process without PyTorch: librccl is found by the library itself
+    one, plain = str(tmp_path / "one.png"), str(tmp_path / "plain.png")
+    for extra, dst in ((["--gpus", "1", "--reduce", "rccl"], one), ([], plain)):
+        r = subprocess.run([exe, "-i", obj, "-o", dst, "-s", "48x40", "-m", "6", "-t", "2", "-n", "3", "--seed", "5"] + extra,
+                           capture_output=True, text=True, timeout=180)
+        assert r.returncode == 0, r.stderr
+    assert open(one, "rb").read() == open(plain, "rb").read()
     # more GPUs than the machine has: a clear error, no crash
     n = pt.device_count()
     r = subprocess.run([exe, "-i", obj, "-o", out, "-s", "16x16", "--gpus", str(n + 1)], capture_output=True, text=True, timeout=60)
