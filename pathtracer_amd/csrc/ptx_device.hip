@@ -96,7 +96,7 @@ struct RenderState {
     // [2r+1] = shadow queue of round r.  One atomic add + two atomic max per workgroup and kernel.
     uint32_t* qcounts;
     uint32_t* qmax;
-    uint32_t* cursors;     // [2 * max_bounces] work cursors of the persistent traversal launches
+    uint32_t* cursors;     // [2 * CURSOR_WORDS * rounds] work cursors of the persistent traversal launches
     unsigned long long* totals;  // extend rays, shadow rays, ext inner, ext tris, sh inner, sh tris
     ptx_pinhole cam;
     uint64_t seed;
@@ -259,6 +259,10 @@ constexpr uint32_t TRI_BATCH_ANYHIT = PTX_TRI_BATCH_ANY;
 #ifndef PTX_AUTO_MEMORY_FRACTION
 #define PTX_AUTO_MEMORY_FRACTION 0.5
 #endif
+#ifndef PTX_XCD_WINDOWS
+#define PTX_XCD_WINDOWS 0
+#endif
+constexpr int CURSOR_WORDS = 8;  // one work cursor per XCD (PTX_XCD_WINDOWS), else only the first is used
 constexpr int32_t DESC_EXIT = -1, DESC_IDLE = -2;
 constexpr uint32_t DESC_LEAF = 0x80000000u, DESC_PAYLOAD = 0x3FFFFFFFu;
 constexpr uint32_t DESC_MAX_PAYLOAD = 0x3FFFFFFDu;  // offsets and triangle indices stay below 2^30 - 2
@@ -351,8 +355,19 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
     const uint32_t head_max = max_count > tail ? max_count - tail : 0u;
     const uint32_t wps_a = (head_max + chunk - 1u) / chunk;        // large windows per segment
     const uint32_t wps_b = chunk > 64u ? tail / 64u : 0u;          // 64-ray windows per segment
+#if PTX_XCD_WINDOWS
+    // XCD-aware hand-out: each XCD has a cursor of its own over ITS eighth of every segment's windows (a compact
+    // part of the image for the early bounces, so the XCD's L2 sees an eighth of the rays' footprint), and steals
+    // from the next XCD's list when its own is exhausted.
+    const uint32_t per_a = (wps_a + 7u) / 8u, per_b = (wps_b + 7u) / 8u;
+    const uint32_t n_a = per_a * n_seg;
+    const uint32_t n_windows = n_a + per_b * n_seg;  // in one XCD's list
+    uint32_t xcd = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;  // HW_REG_XCC_ID, bits 3:0
+    uint32_t xcd_tried = 0;
+#else
     const uint32_t n_a = wps_a * n_seg;
     const uint32_t n_windows = n_a + wps_b * n_seg;
+#endif
     uint32_t lo = 0, hi = 0;
     bool drained = false;  // the launch's cursor has passed the last window
     int32_t cur = DESC_IDLE;
@@ -396,6 +411,22 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
             if (lo >= hi) {
                 if (drained) break;
                 uint32_t w = 0;
+#if PTX_XCD_WINDOWS
+                if (lane == 0) w = atomicAdd(a.cursor + xcd, 1u);
+                w = __builtin_amdgcn_readfirstlane(w);
+                if (w >= n_windows) {
+                    if (++xcd_tried == 8u) {
+                        drained = true;
+                        break;
+                    }
+                    xcd = (xcd + 1u) & 7u;
+                    continue;
+                }
+                const bool large = w < n_a;
+                const uint32_t wl = large ? w : w - n_a, per = large ? per_a : per_b;
+                const uint32_t seg = wl / per, k = xcd * per + (wl - seg * per);
+                if (k >= (large ? wps_a : wps_b)) continue;  // the last XCDs' eighths may be short
+#else
                 if (lane == 0) w = atomicAdd(a.cursor, 1u);
                 w = __builtin_amdgcn_readfirstlane(w);
                 if (w >= n_windows) {
@@ -405,6 +436,7 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                 const bool large = w < n_a;
                 const uint32_t wl = large ? w : w - n_a, per = large ? wps_a : wps_b;
                 const uint32_t seg = wl / per, k = wl - seg * per;
+#endif
                 const uint32_t cnt = segmented ? a.seg_counts[seg] * a.count_scale : a.fixed_count;
                 const uint32_t head = cnt > tail ? cnt - tail : 0u;  // rays of this segment handed out in large windows
                 const uint32_t first = large ? k * chunk : head + k * 64u;
@@ -1327,7 +1359,7 @@ int grow_render_state(ptx_scene* sc, size_t slots, size_t paths, uint32_t rounds
         if (L > 1) HIP_TRY(p.sh_contrib.ensure(slots * L));
         HIP_TRY(p.sh_occ.ensure(slots * L));
         HIP_TRY(p.sh_bounce.ensure(slots));
-        HIP_TRY(p.counts.ensure(6 * (size_t)rounds + 4));
+        HIP_TRY(p.counts.ensure((4 + 2 * CURSOR_WORDS) * (size_t)rounds + 4));
         HIP_TRY(p.segs.ensure(4 * (size_t)sc->shade_grid));
     }
     if (!sc->totals.p) {
@@ -1654,7 +1686,7 @@ int ptx_scene_create(const ptx_scene_desc* d, uint32_t flags, ptx_scene** out) {
     HIP_TRY(sc->totals.ensure(32));
     HIP_TRY(hipMemset(sc->totals.p, 0, 32 * sizeof(unsigned long long)));
     HIP_TRY(sc->spill.ensure((size_t)(PTX_MAX_DEPTH - LDS_DEPTH) * sc->tgrid * TBLOCK));
-    HIP_TRY(sc->batch_cursor.ensure(1));
+    HIP_TRY(sc->batch_cursor.ensure(CURSOR_WORDS));
     HIP_TRY(hipEventCreateWithFlags(&sc->ev_batch, hipEventDisableTiming));
     {
         // the scratch array of the allocation-free entry point: its address on THIS device (every GPU holds
@@ -1721,7 +1753,7 @@ int ptx_intersect_batch_device(ptx_scene* sc, const ptx_ray* d_rays, size_t n, p
         Timed tm(sc, (hipStream_t)stream, KC_EXTEND);
         sc->batch_extend_rays += n;
         ++sc->extend_launches;
-        HIP_TRY(hipMemsetAsync(sc->batch_cursor.p, 0, sizeof(uint32_t), (hipStream_t)stream));
+        HIP_TRY(hipMemsetAsync(sc->batch_cursor.p, 0, CURSOR_WORDS * sizeof(uint32_t), (hipStream_t)stream));
         rc = launch_traverse<false>(sc, d_rays, SegRange{}, (uint32_t)n, d_hits, nullptr, sc->batch_cursor.p, sc->spill.p,
                                     sc->totals.p + 2, (hipStream_t)stream);
     }
@@ -1742,7 +1774,7 @@ int ptx_intersect_batch_device_noalloc(ptx_scene* sc, const ptx_ray* d_rays, siz
     // No allocation, no event, no timing bracket: a memset node and one kernel launch on the caller's stream.
     sc->batch_extend_rays += n;
     ++sc->extend_launches;
-    HIP_TRY(hipMemsetAsync(ptr, 0, sizeof(uint32_t), (hipStream_t)stream));  // the cursor must start at zero
+    HIP_TRY(hipMemsetAsync(ptr, 0, CURSOR_WORDS * sizeof(uint32_t), (hipStream_t)stream));  // the cursors must start at zero
     return launch_traverse<false>(sc, d_rays, SegRange{}, (uint32_t)n, d_hits, nullptr, reinterpret_cast<uint32_t*>(ptr),
                                   reinterpret_cast<uint2*>(ptr + 256), sc->totals.p + 2, (hipStream_t)stream, NOALLOC_GRID);
 }
@@ -1758,7 +1790,7 @@ int ptx_occluded_batch_device(ptx_scene* sc, const ptx_ray* d_rays, size_t n, ui
         Timed tm(sc, (hipStream_t)stream, KC_SHADOW);
         sc->batch_shadow_rays += n;
         ++sc->shadow_launches;
-        HIP_TRY(hipMemsetAsync(sc->batch_cursor.p, 0, sizeof(uint32_t), (hipStream_t)stream));
+        HIP_TRY(hipMemsetAsync(sc->batch_cursor.p, 0, CURSOR_WORDS * sizeof(uint32_t), (hipStream_t)stream));
         rc = launch_traverse<true>(sc, d_rays, SegRange{}, (uint32_t)n, nullptr, d_out, sc->batch_cursor.p, sc->spill.p,
                                    sc->totals.p + 4, (hipStream_t)stream);
     }
@@ -1967,7 +1999,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         st.n_samples = ns;
         st.n_paths = ns * n_pixels;
         st.first_sample = first_sample + done;
-        HIP_TRY(hipMemsetAsync(p.counts.p, 0, (6 * (size_t)rounds + 4) * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(p.counts.p, 0, ((4 + 2 * CURSOR_WORDS) * (size_t)rounds + 4) * sizeof(uint32_t), stream));
         if (rounds == 0) {  // max_bounces == 0: nothing is traced (the reference's loop body never runs)
             HIP_TRY(hipMemsetAsync(p.radiance.p, 0, (size_t)st.n_paths * sizeof(Rad), stream));
         } else {
@@ -1987,7 +2019,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
                 sr.n_seg = n_seg;
                 sr.cap = seg_cap;
                 sr.internal = true;
-                rc = launch_traverse<false>(sc, st.rays[(b - 1) & 1], sr, 0, st.hits, nullptr, st.cursors + 2 * (b - 1),
+                rc = launch_traverse<false>(sc, st.rays[(b - 1) & 1], sr, 0, st.hits, nullptr, st.cursors + 2 * CURSOR_WORDS * (b - 1),
                                             p.spill.p, sc->totals.p + 2, stream);
                 if (rc) return rc;
                 if (sc->flags & PTX_FLAG_CHECK_BRUTE) launch_check(sc, st.rays[(b - 1) & 1], sr, st.hits, nullptr, stream);
@@ -2017,7 +2049,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
                     sr.n_seg = n_seg;
                     sr.cap = seg_cap;
                     sr.scale = L;
-                    rc = launch_traverse<true>(sc, st.sh_rays, sr, 0, nullptr, st.sh_occ, st.cursors + 2 * (b - 1) + 1, sspill,
+                    rc = launch_traverse<true>(sc, st.sh_rays, sr, 0, nullptr, st.sh_occ, st.cursors + 2 * CURSOR_WORDS * (b - 1) + CURSOR_WORDS, sspill,
                                                sc->totals.p + 4, sstream);
                     if (rc) return rc;
                     if (sc->flags & PTX_FLAG_CHECK_BRUTE) launch_check(sc, st.sh_rays, sr, nullptr, st.sh_occ, sstream);
