@@ -132,6 +132,8 @@ typedef struct ptx_scene ptx_scene; /* opaque: device-resident scene (one GPU) *
 #define PTX_FLAG_COUNT_WORK 1u   /* count node visits / triangle tests in the traversal kernels */
 #define PTX_FLAG_TIME_KERNELS 2u /* bracket each kernel class with HIP events inside ptx_render */
 #define PTX_FLAG_CHECK_BRUTE 4u  /* re-intersect every ray of ptx_render against all triangles (see ptx_check_report) */
+#define PTX_FLAG_MATERIAL_QUEUES 8u /* shade the entries of every queue segment grouped by the material they hit (SURVEY 8f-1;
+                                       same images bit for bit; measured slower than queue order, off by default: DESIGN.md 8) */
 
 const char* ptx_last_error(void);
 const char* ptx_version(void);

@@ -26,6 +26,7 @@ MAX_LIGHTS = 8
 FLAG_COUNT_WORK = 1
 FLAG_TIME_KERNELS = 2
 FLAG_CHECK_BRUTE = 4
+FLAG_MATERIAL_QUEUES = 8
 
 
 class PtxError(RuntimeError):

@@ -77,6 +77,7 @@ struct RenderState {
     float4* sh_contrib;  // [i * n_lights + l] {bsdf * emitted * |cos|, 0}
     uint8_t* sh_occ;     // [i * n_lights + l] 1 = occluded
     uint8_t* sh_bounce;  // [i] bounce of the path that shot the shadow rays; only while the ray log is on, else null
+    uint32_t* perm;      // [slot] PTX_FLAG_MATERIAL_QUEUES: the order in which k_shade takes the entries of a segment (by material of the hit), else null
     // Queues are SEGMENTED: segment s owns slots [s * seg_cap, (s + 1) * seg_cap) of every queue for the
     // whole batch; k_start fills the segments in path order, and workgroup s of k_shade / k_resolve reads
     // segment s and compacts its survivors to the front of segment s of the output queue with a counter of
@@ -731,6 +732,62 @@ __device__ inline Bsdf material_sample(const DevMaterial& m, V3 wi, V3 n, float 
     return Bsdf{true, 0.0f, v3(0, 0, 0), n};
 }
 
+// Material-keyed shade queues (second half; PTX_FLAG_MATERIAL_QUEUES): after the extend launch the
+// entries of every queue segment are bucketed by the material of the triangle they hit (bucket 0 = miss, then
+// material id + 1, ids >= 6 share the last bucket), stably, and k_shade takes them bucket by bucket: the 64 paths of a
+// wave then share a material, hence a lobe set (`Material::sample`, material.rs:167-191) and the texture branch.
+// Only the ORDER of shading changes; every path is shaded with its own numbers, so images stay bit-identical.
+// Two passes over the segment per workgroup (bucket totals, then positions): ballots per bucket, no atomics.
+constexpr int MQ_BUCKETS = 8;
+__global__ __launch_bounds__(BLOCK) void k_bucket(DevScene sc, RenderState st, uint32_t q) {
+    __shared__ uint32_t s_wave[WAVES][MQ_BUCKETS];
+    __shared__ uint32_t s_run[MQ_BUCKETS];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (uint32_t seg = blockIdx.x; seg < st.n_seg; seg += gridDim.x) {
+        const uint32_t count = st.seg_ext[q][seg], seg_base = seg * st.seg_cap;
+        for (int pass = 0; pass < 2; ++pass) {
+            __syncthreads();
+            uint32_t first_pos = 0;  // pass 1: totals -> first position of every bucket (read, barrier, then write)
+            if (pass == 1 && threadIdx.x < MQ_BUCKETS)
+                for (uint32_t b = 0; b < (uint32_t)MQ_BUCKETS; ++b) first_pos += b < threadIdx.x ? s_run[b] : 0u;
+            __syncthreads();
+            if (threadIdx.x < MQ_BUCKETS) s_run[threadIdx.x] = first_pos;
+            __syncthreads();
+            for (uint32_t start = 0; start < count; start += BLOCK) {
+                const uint32_t k = start + threadIdx.x;
+                uint32_t key = MQ_BUCKETS;  // inactive lane
+                if (k < count) {
+                    const uint32_t idx = reinterpret_cast<const uint4*>(st.hits)[seg_base + k].x;
+                    key = 0;
+                    if (idx != PTX_MISS) {
+                        const uint32_t m = f2u(sc.props[4 * (size_t)idx + 3].w) + 1u;
+                        key = m < (uint32_t)MQ_BUCKETS ? m : (uint32_t)MQ_BUCKETS - 1u;
+                    }
+                }
+                uint32_t rank = 0;
+                for (uint32_t b = 0; b < (uint32_t)MQ_BUCKETS; ++b) {
+                    const unsigned long long m = __ballot(key == b);
+                    if (key == b) rank = (uint32_t)__popcll(m & lt);
+                    if (lane == b) s_wave[wave][b] = (uint32_t)__popcll(m);
+                }
+                __syncthreads();
+                if (pass == 1 && key < (uint32_t)MQ_BUCKETS) {
+                    uint32_t at = s_run[key] + rank;
+                    for (uint32_t w = 0; w < wave; ++w) at += s_wave[w][key];
+                    st.perm[seg_base + at] = k;
+                }
+                uint32_t chunk_total = 0;  // every read of s_wave and s_run happens before the barrier, the update after it
+                if (threadIdx.x < MQ_BUCKETS)
+                    for (int w = 0; w < WAVES; ++w) chunk_total += s_wave[w][threadIdx.x];
+                __syncthreads();
+                if (threadIdx.x < MQ_BUCKETS) s_run[threadIdx.x] += chunk_total;
+                // (the next chunk reads s_run only after its own barrier)
+            }
+        }
+    }
+}
+
 // One bounce of trace_ray (pathtracer.rs:33-108) for every entry of the current extend queue.
 template <int NL /* compile-time light count, 0 = read it from the scene */>
 __global__ __launch_bounds__(BLOCK, PTX_SHADE_WAVES) void k_shade(DevScene sc, RenderState st, uint32_t round /* 1-based */) {
@@ -751,8 +808,9 @@ __global__ __launch_bounds__(BLOCK, PTX_SHADE_WAVES) void k_shade(DevScene sc, R
     uint32_t n_next = 0, n_shadow = 0;
     __syncthreads();  // everybody has read seg_next before thread 0 rewrites it below
     for (uint32_t start = 0; start < count; start += BLOCK) {
-        const uint32_t i = seg_base + start + threadIdx.x;
         const bool active = start + threadIdx.x < count;
+        // entry of this lane: in queue order, or (material-keyed queues) in the order k_bucket laid down
+        const uint32_t i = seg_base + (st.perm && active ? st.perm[seg_base + start + threadIdx.x] : start + threadIdx.x);
         bool emit_next = false, emit_shadow = false;
         uint32_t pid = 0, bounce = 1;
         V3 next_o = v3(0, 0, 0), next_d = v3(0, 0, 0), point_above = v3(0, 0, 0), T_old = v3(0, 0, 0), T_next = v3(0, 0, 0);
@@ -1201,6 +1259,7 @@ struct ptx_scene {
         DevBuf<Rad> radiance;
         DevBuf<ptx_ray> sh_rays;
         DevBuf<uint8_t> sh_occ, sh_bounce;
+        DevBuf<uint32_t> perm;  // PTX_FLAG_MATERIAL_QUEUES
         DevBuf<uint2> spill;
         DevBuf<uint32_t> counts, segs;
         ~Pipe() {
@@ -1359,6 +1418,7 @@ int grow_render_state(ptx_scene* sc, size_t slots, size_t paths, uint32_t rounds
         if (L > 1) HIP_TRY(p.sh_contrib.ensure(slots * L));
         HIP_TRY(p.sh_occ.ensure(slots * L));
         HIP_TRY(p.sh_bounce.ensure(slots));
+        if (sc->flags & PTX_FLAG_MATERIAL_QUEUES) HIP_TRY(p.perm.ensure(slots));
         HIP_TRY(p.counts.ensure((4 + 2 * CURSOR_WORDS) * (size_t)rounds + 4));
         HIP_TRY(p.segs.ensure(4 * (size_t)sc->shade_grid));
     }
@@ -1538,7 +1598,7 @@ uint64_t held_queue_bytes(const ptx_scene* sc) {
         const ptx_scene::Pipe& p = *up;
         b += (p.rays[0].n + p.rays[1].n + p.sh_rays.n) * sizeof(ptx_ray) + p.hits.n * sizeof(ptx_hit);
         b += (p.transq[0].n + p.transq[1].n + p.sh_T.n + p.sh_contrib.n) * sizeof(float4) + p.radiance.n * sizeof(Rad);
-        b += p.sh_occ.n + p.sh_bounce.n + (p.spill.n + p.spill2.n) * sizeof(uint2) + (p.counts.n + p.segs.n) * sizeof(uint32_t);
+        b += p.perm.n * sizeof(uint32_t) + p.sh_occ.n + p.sh_bounce.n + (p.spill.n + p.spill2.n) * sizeof(uint2) + (p.counts.n + p.segs.n) * sizeof(uint32_t);
     }
     return b;
 }
@@ -1980,6 +2040,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         st.sh_contrib = p.sh_contrib.p;
         st.sh_occ = p.sh_occ.p;
         st.sh_bounce = sc->raylog_cap ? p.sh_bounce.p : nullptr;
+        st.perm = (sc->flags & PTX_FLAG_MATERIAL_QUEUES) ? p.perm.p : nullptr;
         st.qcounts = p.counts.p;
         st.qmax = p.counts.p + (2 * rounds + 2);
         st.cursors = p.counts.p + (4 * rounds + 4);
@@ -2030,6 +2091,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
             {
                 Timed tm(sc, stream, KC_SHADE);
                 const int sg = (int)n_seg;
+                if (st.perm) k_bucket<<<sg, BLOCK, 0, stream>>>(sc->dev, st, (b - 1) & 1);  // (its time counts as shading)
                 if (L == 1) k_shade<1><<<sg, BLOCK, 0, stream>>>(sc->dev, st, b);
                 else if (L == 2) k_shade<2><<<sg, BLOCK, 0, stream>>>(sc->dev, st, b);
                 else if (L == 4) k_shade<4><<<sg, BLOCK, 0, stream>>>(sc->dev, st, b);

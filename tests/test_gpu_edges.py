@@ -258,3 +258,29 @@ def test_device_tonemap_equals_the_host_tonemap():
         assert diff.max() <= 1 and (diff != 0).mean() < 1e-5
         assert list(got[:12]) == list(want[:12]) and got[0] == 0 and got[3] == 255  # zero, negative, NaN (`min` keeps the 1.0), inf, ...
     dev.close()
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("cornell_textured", 160, 120, 6), ("sr2", 128, 72, 4), ("cornell_teapot", 96, 96, 3)])
+def test_material_keyed_shade_queues_change_no_bit(name, w, h, spp):
+    """SURVEY 8f-1, second half: with PTX_FLAG_MATERIAL_QUEUES the entries of every queue segment are shaded grouped by
+    the material they hit (k_bucket + a permuted k_shade).  Only the order of shading changes: same image, bit for bit,
+    with plain batches, with path regeneration, and in a tile."""
+    import torch
+
+    scene = pt.LoadedScene(os.path.join(SCENES, name + ".obj"), max_bounces=8)
+    plain, keyed = scene.upload(), scene.upload(flags=pt.FLAG_MATERIAL_QUEUES)
+    ph = scene.pinhole(w, h)
+    want = plain.render(ph, spp, seed=6)
+    assert keyed.render(ph, spp, seed=6).tobytes() == want.tobytes()
+    keyed.set_queue_slots(4096)  # far fewer slots than paths: regeneration rounds mix bounces inside a segment
+    assert keyed.render(ph, spp, seed=6).tobytes() == want.tobytes()
+    keyed.set_queue_slots(0)
+    stream = torch.cuda.current_stream().cuda_stream
+    a = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
+    b = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
+    plain.render_region_device(ph, 8, 16, 40, 24, spp, a.data_ptr(), seed=6, stream=stream)
+    keyed.render_region_device(ph, 8, 16, 40, 24, spp, b.data_ptr(), seed=6, stream=stream)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    plain.close()
+    keyed.close()
