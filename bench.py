@@ -178,6 +178,13 @@ def main():
             ext_ms, sh_ms = st["extend_ms"], st["shadow_ms"]
             out["extend_mrays_per_s"] = st["extend_rays"] / ext_ms / 1e3
             out["shadow_mrays_per_s"] = st["shadow_rays"] / sh_ms / 1e3 if sh_ms > 0 else None
+            if st["extend_launches"] == args.steps * args.max_bounces:
+                # no path regeneration: round r is bounce r, and every path shoots exactly one camera ray
+                r_ext, _ = dev.round_times(args.max_bounces)
+                camera_rays = float(args.steps) * W * H * spp
+                if r_ext[0] > 0 and ext_ms > r_ext[0]:
+                    out["extend_camera_mrays_per_s"] = camera_rays / r_ext[0] / 1e3
+                    out["extend_bounced_mrays_per_s"] = (st["extend_rays"] - camera_rays) / (ext_ms - r_ext[0]) / 1e3
             out["kernel_ms"] = {"extend": ext_ms, "shadow": sh_ms, "shade": st["shade_ms"], "generate": st["generate_ms"], "resolve_accumulate": st["other_ms"]}
             # algorithmic bytes per extend ray: 32 ray + 16 hit + 8 per inner node + 40 per triangle test,
             # node/triangle counts measured on this workload by a counting pass outside the timed region

@@ -337,6 +337,10 @@ int ptx_tonemap_rgb8_device(const float* d_accum, uint32_t width, uint32_t heigh
  * bounce r; shadow counts are paths: multiply by the number of lights).  n = capacity of each array. */
 int ptx_last_batch_counts(ptx_scene* scene, uint32_t* extend_counts, uint32_t* shadow_counts, uint32_t n);
 int ptx_stats(ptx_scene* scene, ptx_counters* out);
+/* Kernel time of the extend / shadow launches per round since ptx_stats_reset (scenes created with
+ * PTX_FLAG_TIME_KERNELS): extend_ms[r], shadow_ms[r] = round r + 1.  Without path regeneration round r is bounce r, so
+ * round 1 is the camera rays: SURVEY 8d asks for camera, bounced and shadow rays separately.  n = array capacity. */
+int ptx_round_times(ptx_scene* scene, double* extend_ms, double* shadow_ms, uint32_t n);
 int ptx_stats_reset(ptx_scene* scene);
 
 /* `kdtree-tester-cli test` on the GPU (kdtree-tester-cli/src/ray_tester.rs, ray_bouncer.rs:35-56): a scene

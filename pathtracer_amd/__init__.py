@@ -440,6 +440,13 @@ class DeviceScene:
         _check(lib().ptx_stats(self._h, C.byref(c)))
         return c.as_dict()
 
+    def round_times(self, n=None):
+        """(extend ms, shadow ms) per round since stats_reset (FLAG_TIME_KERNELS); round 1 = camera rays."""
+        n = n or max(self.max_bounces, 1)
+        e, s = np.zeros(n, np.float64), np.zeros(n, np.float64)
+        _check(lib().ptx_round_times(self._h, _ptr(e), _ptr(s), n))
+        return e, s
+
     def last_batch_counts(self):
         n = 8 * max(self.max_bounces, 1)  # rounds: up to 8 slot-loads of paths per batch
         e, s = np.zeros(n, np.uint32), np.zeros(n, np.uint32)

@@ -1301,7 +1301,9 @@ struct ptx_scene {
     struct Stamp {
         hipEvent_t a, b;
         int cls;
+        uint32_t round;  // 1-based round of the batch for the traversal launches of a render, else 0
     };
+    std::vector<double> round_ms[2];  // [0] extend, [1] shadow: kernel time per round since the last reset
     std::vector<Stamp> stamps;
     std::vector<hipEvent_t> free_events;
     double class_ms[KC_COUNT] = {0, 0, 0, 0, 0};
@@ -1342,11 +1344,12 @@ struct Timed {  // RAII bracket of one launch with two events when timing is on
     hipStream_t stream;
     ptx_scene::Stamp st{};
     bool on;
-    Timed(ptx_scene* s, hipStream_t str, int cls) : sc(s), stream(str), on((s->flags & PTX_FLAG_TIME_KERNELS) != 0) {
+    Timed(ptx_scene* s, hipStream_t str, int cls, uint32_t round = 0) : sc(s), stream(str), on((s->flags & PTX_FLAG_TIME_KERNELS) != 0) {
         if (on) {
             st.a = take_event(sc);
             st.b = take_event(sc);
             st.cls = cls;
+            st.round = round;
             (void)hipEventRecord(st.a, stream);
         }
     }
@@ -1358,6 +1361,15 @@ struct Timed {  // RAII bracket of one launch with two events when timing is on
     }
 };
 
+void book_stamp(ptx_scene* sc, const ptx_scene::Stamp& s, float ms) {
+    sc->class_ms[s.cls] += ms;
+    if (s.round && (s.cls == KC_EXTEND || s.cls == KC_SHADOW)) {
+        std::vector<double>& v = sc->round_ms[s.cls == KC_EXTEND ? 0 : 1];
+        if (v.size() < s.round) v.resize(s.round, 0.0);
+        v[s.round - 1] += ms;
+    }
+}
+
 // Without anybody asking for ptx_stats a long-running render loop would pile up stamps (two events per launch):
 // past a threshold the finished ones are folded into the class totals and their events recycled.
 void clear_stale_stamps(ptx_scene* sc) {
@@ -1366,7 +1378,7 @@ void clear_stale_stamps(ptx_scene* sc) {
     for (auto& s : sc->stamps) {
         float ms = 0.0f;
         if (hipEventQuery(s.b) == hipSuccess) {
-            if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) sc->class_ms[s.cls] += ms;
+            if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) book_stamp(sc, s, ms);
             sc->free_events.push_back(s.a);
             sc->free_events.push_back(s.b);
         } else {
@@ -1379,8 +1391,7 @@ void clear_stale_stamps(ptx_scene* sc) {
 void resolve_stamps(ptx_scene* sc) {
     for (auto& s : sc->stamps) {
         float ms = 0.0f;
-        if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess)
-            sc->class_ms[s.cls] += ms;
+        if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) book_stamp(sc, s, ms);
         sc->free_events.push_back(s.a);
         sc->free_events.push_back(s.b);
     }
@@ -2072,7 +2083,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         uint2* sspill = overlap ? p.spill2.p : p.spill.p;
         for (uint32_t b = 1; b <= rounds; ++b) {
             {
-                Timed tm(sc, stream, KC_EXTEND);
+                Timed tm(sc, stream, KC_EXTEND, b);
                 ++sc->extend_launches;
                 SegRange sr;
                 sr.counts = st.seg_ext[(b - 1) & 1];
@@ -2103,7 +2114,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
                     HIP_TRY(hipStreamWaitEvent(sstream, p.ev_shade, 0));
                 }
                 {
-                    Timed tm(sc, sstream, KC_SHADOW);
+                    Timed tm(sc, sstream, KC_SHADOW, b);
                     ++sc->shadow_launches;
                     SegRange sr;
                     sr.counts = st.seg_sh;
@@ -2274,6 +2285,19 @@ int ptx_stats(ptx_scene* sc, ptx_counters* out) {
     return PTX_OK;
 }
 
+int ptx_round_times(ptx_scene* sc, double* extend_ms, double* shadow_ms, uint32_t n) {
+    int rc = check_scene(sc, "ptx_round_times");
+    if (rc) return rc;
+    if (!extend_ms || !shadow_ms) return fail(PTX_E_ARG, "ptx_round_times: null argument");
+    HIP_TRY(hipDeviceSynchronize());
+    resolve_stamps(sc);
+    for (uint32_t r = 0; r < n; ++r) {
+        extend_ms[r] = r < sc->round_ms[0].size() ? sc->round_ms[0][r] : 0.0;
+        shadow_ms[r] = r < sc->round_ms[1].size() ? sc->round_ms[1][r] : 0.0;
+    }
+    return PTX_OK;
+}
+
 int ptx_debug_loop_profile(ptx_scene* sc, uint64_t* out24) {
     int rc = check_scene(sc, "ptx_debug_loop_profile");
     if (rc) return rc;
@@ -2379,6 +2403,8 @@ int ptx_stats_reset(ptx_scene* sc) {
     resolve_stamps(sc);
     HIP_TRY(hipMemset(sc->totals.p, 0, 32 * sizeof(unsigned long long)));
     for (double& v : sc->class_ms) v = 0;
+    sc->round_ms[0].clear();
+    sc->round_ms[1].clear();
     sc->total_ms = 0;
     sc->samples_done = 0;
     sc->batch_extend_rays = sc->batch_shadow_rays = 0;
