@@ -1,5 +1,6 @@
 #!/bin/bash
-# probe: k_shade workgroup size (PTX_BLOCK) at equal waves per CU
+# probe: k_shade workgroup size (-DPTX_BLOCK variants built with tools/build_variants.sh) at a stated number of
+# workgroups per CU.  usage (GPU box): bash tools/shade_block_probe.sh "name lib per_cu" ...
 OUT=gpurun_out/r2blk; mkdir -p $OUT
 V=$PWD/pathtracer_amd/lib/variants
 run() { # name lib per_cu
@@ -9,4 +10,4 @@ import json
 d=json.load(open('$OUT/bench_$1.json')); k=d['kernel_ms']
 print('%-16s samples/s %6.1fM  extend %6.1f shadow %6.1f shade %6.1f start %5.1f resolve+acc %5.1f ms'%('$1',d['value']/1e6,k['extend'],k['shadow'],k['shade'],k['generate'],k['resolve_accumulate']))" | tee -a $OUT/variants.txt
 }
-run ref_5 ref 5 && run b128_10 b128 10 && run b64_20 b64 20 && run ref_5b ref 5 && run b128_10b b128 10 && run b64_20b b64 20
+for spec in "$@"; do run $spec || exit 1; done
