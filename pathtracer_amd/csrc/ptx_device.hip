@@ -269,6 +269,55 @@ constexpr uint32_t DESC_LEAF = 0x80000000u, DESC_PAYLOAD = 0x3FFFFFFFu;
 constexpr uint32_t DESC_MAX_PAYLOAD = 0x3FFFFFFDu;  // offsets and triangle indices stay below 2^30 - 2
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Queue entries (rays, hits, transport, shadow records) are written once by one kernel and read once by the next:
+// marked non-temporal so that they stream through the L2 instead of evicting the tree and the triangle records the
+// traversal lives on (extend -2.5 %, shadow -1.7 % time; profiles/r02_loop_variants.txt).  Full 16-byte entries
+// only: the same hint on the 12-byte read-modify-writes of the per-path radiance and on k_start's stores costs
+// more than it saves (resolve +20 %, start x2).
+#ifndef PTX_STREAM_HINT
+#define PTX_STREAM_HINT 1
+#endif
+__device__ __forceinline__ float4 ld_stream(const float4* p) {
+#if PTX_STREAM_HINT
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ uint4 ld_stream(const uint4* p) {
+#if PTX_STREAM_HINT
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void st_stream(float4* p, float4 v) {
+#if PTX_STREAM_HINT
+    f32x4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<f32x4*>(p));
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void st_stream(uint4* p, uint4 v) {
+#if PTX_STREAM_HINT
+    u32x4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(p));
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void st_stream(uint8_t* p, uint8_t v) {
+#if PTX_STREAM_HINT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 
 // Scratch of ptx_intersect_batch_device_noalloc (include/ptx.h): the launch's work cursor (first 256 bytes) and
 // the spill levels of the traversal stacks of NOALLOC_GRID workgroups.  File-scope device memory: every GPU the
@@ -399,9 +448,9 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
             if (ANY) {
                 // (resolving here - radiance[path] += contribution for an unoccluded ray - was measured slower
                 // than the separate streaming k_resolve: the scattered read-modify-write stalls the whole wave)
-                a.occ[ridx] = bi != PTX_MISS ? 1 : 0;
+                st_stream(a.occ + ridx, (uint8_t)(bi != PTX_MISS ? 1 : 0));
             } else {
-                reinterpret_cast<uint4*>(a.hits)[ridx] = make_uint4(bi, f2u(bt), f2u(bu), f2u(bv));
+                st_stream(reinterpret_cast<uint4*>(a.hits) + ridx, make_uint4(bi, f2u(bt), f2u(bu), f2u(bv)));
             }
             ridx = NO_RAY;
         }
@@ -452,8 +501,8 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
             const uint32_t avail = hi - lo;
             if (cur == DESC_IDLE && rank < avail) {
                 ridx = lo + rank;
-                const float4 ra = reinterpret_cast<const float4*>(a.rays)[2 * (size_t)ridx];
-                const float4 rb = reinterpret_cast<const float4*>(a.rays)[2 * (size_t)ridx + 1];
+                const float4 ra = ld_stream(reinterpret_cast<const float4*>(a.rays) + 2 * (size_t)ridx);
+                const float4 rb = ld_stream(reinterpret_cast<const float4*>(a.rays) + 2 * (size_t)ridx + 1);
                 ox = ra.x, oy = ra.y, oz = ra.z, t1 = a.internal ? 0.0f : ra.w;
                 dx = rb.x, dy = rb.y, dz = rb.z, t2 = t_end = a.internal ? 3.402823466e+38f : rb.w;
                 cur = a.root;
@@ -816,16 +865,16 @@ __global__ __launch_bounds__(BLOCK, PTX_SHADE_WAVES) void k_shade(DevScene sc, R
         V3 next_o = v3(0, 0, 0), next_d = v3(0, 0, 0), point_above = v3(0, 0, 0), T_old = v3(0, 0, 0), T_next = v3(0, 0, 0);
         V3 sh_dir[MAXL], sh_c[MAXL];
         if (active) {
-            const float4 ra = reinterpret_cast<const float4*>(rays_in)[2 * (size_t)i];
-            const float4 rb = reinterpret_cast<const float4*>(rays_in)[2 * (size_t)i + 1];
+            const float4 ra = ld_stream(reinterpret_cast<const float4*>(rays_in) + 2 * (size_t)i);
+            const float4 rb = ld_stream(reinterpret_cast<const float4*>(rays_in) + 2 * (size_t)i + 1);
             pid = f2u(ra.w);
             bounce = f2u(rb.w);  // 1-based: the bounce this ray has just traced
             const uint32_t base = ptx_dim_base(bounce, n_lights);
-            const uint4 hraw = reinterpret_cast<const uint4*>(st.hits)[i];
+            const uint4 hraw = ld_stream(reinterpret_cast<const uint4*>(st.hits) + i);
             // accumulated_transport = Vec3::ONE at the first bounce (pathtracer.rs:31): not stored by start_path
             V3 T = v3(1.0f, 1.0f, 1.0f);
             if (bounce != 1u) {
-                const float4 Traw = st.transq[q][i];
+                const float4 Traw = ld_stream(st.transq[q] + i);
                 T = v3(Traw.x, Traw.y, Traw.z);
             }
             if (hraw.x == PTX_MISS) {
@@ -900,21 +949,21 @@ __global__ __launch_bounds__(BLOCK, PTX_SHADE_WAVES) void k_shade(DevScene sc, R
         n_next += tot_n;
         n_shadow += tot_s;
         if (emit_next) {
-            reinterpret_cast<float4*>(rays_out)[2 * (size_t)slot_n] = make_float4(next_o.x, next_o.y, next_o.z, u2f(pid));
-            reinterpret_cast<float4*>(rays_out)[2 * (size_t)slot_n + 1] = make_float4(next_d.x, next_d.y, next_d.z, u2f(bounce + 1u));
-            st.transq[q ^ 1u][slot_n] = make_float4(T_next.x, T_next.y, T_next.z, 0.0f);
+            st_stream(reinterpret_cast<float4*>(rays_out) + 2 * (size_t)slot_n, make_float4(next_o.x, next_o.y, next_o.z, u2f(pid)));
+            st_stream(reinterpret_cast<float4*>(rays_out) + 2 * (size_t)slot_n + 1, make_float4(next_d.x, next_d.y, next_d.z, u2f(bounce + 1u)));
+            st_stream(st.transq[q ^ 1u] + slot_n, make_float4(T_next.x, T_next.y, T_next.z, 0.0f));
         }
         if (emit_shadow) {
             // one light: the record is the product k_resolve would form (0 + c == c, so T * (0 + c) == T * c
             // bit for bit) and no separate contribution array is written
-            if (NL == 1) st.sh_T[slot_s] = make_float4(T_old.x * sh_c[0].x, T_old.y * sh_c[0].y, T_old.z * sh_c[0].z, u2f(pid));
-            else st.sh_T[slot_s] = make_float4(T_old.x, T_old.y, T_old.z, u2f(pid));
+            if (NL == 1) st_stream(st.sh_T + slot_s, make_float4(T_old.x * sh_c[0].x, T_old.y * sh_c[0].y, T_old.z * sh_c[0].z, u2f(pid)));
+            else st_stream(st.sh_T + slot_s, make_float4(T_old.x, T_old.y, T_old.z, u2f(pid)));
             if (st.sh_bounce) st.sh_bounce[slot_s] = (uint8_t)bounce;
             for (uint32_t l = 0; l < (NL ? (uint32_t)NL : n_lights); ++l) {
                 const size_t j = (size_t)slot_s * n_lights + l;
-                reinterpret_cast<float4*>(st.sh_rays)[2 * j] = make_float4(point_above.x, point_above.y, point_above.z, 0.0f);
-                reinterpret_cast<float4*>(st.sh_rays)[2 * j + 1] = make_float4(sh_dir[l].x, sh_dir[l].y, sh_dir[l].z, 1.0f);
-                if (NL != 1) st.sh_contrib[j] = make_float4(sh_c[l].x, sh_c[l].y, sh_c[l].z, 0.0f);
+                st_stream(reinterpret_cast<float4*>(st.sh_rays) + 2 * j, make_float4(point_above.x, point_above.y, point_above.z, 0.0f));
+                st_stream(reinterpret_cast<float4*>(st.sh_rays) + 2 * j + 1, make_float4(sh_dir[l].x, sh_dir[l].y, sh_dir[l].z, 1.0f));
+                if (NL != 1) st_stream(st.sh_contrib + j, make_float4(sh_c[l].x, sh_c[l].y, sh_c[l].z, 0.0f));
             }
         }
     }
@@ -940,7 +989,7 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(RenderState st, uint32_t boun
     for (uint32_t seg = blockIdx.x; seg < st.n_seg; seg += gridDim.x)
     for (uint32_t k = threadIdx.x, count = st.seg_sh[seg]; k < count; k += BLOCK) {
         const uint32_t i = seg * st.seg_cap + k;
-        const float4 T = st.sh_T[i];
+        const float4 T = ld_stream(st.sh_T + i);
         const uint32_t pid = f2u(T.w);
         if (n_lights == 1u) {  // k_shade<1> stored transport * contribution
             if (!st.sh_occ[i]) {
