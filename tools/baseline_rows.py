@@ -27,6 +27,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--threads", type=int, default=min(16, os.cpu_count() or 1))
     ap.add_argument("--no-gpu", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="GPU numbers only (after a kernel change)")
     args = ap.parse_args()
     import pathtracer_amd as pt
     import pyoracle as orc
@@ -41,19 +42,23 @@ def main():
         st = scene.kdtree().stats()
         row = {"run": run, "scene": name, "size": "%dx%d" % (w, h), "triangles": scene.n_triangles, "load_and_build_s": load_build_s,
                "tree": {k: (float(v) if isinstance(v, float) else int(v)) for k, v in st.items()}}
-        ref = orc.Scene(obj)
+        ref = None if args.no_cpu else orc.Scene(obj)
         T = args.threads
-        _, secs, rs = ref.render(w, h, threads=T, iterations_per_thread=n_iter, mode=0, seed=1, stats=True)
-        row["cpu"] = {"kind": "port (oracle, C++ restatement, -O2 -ffp-contract=off)", "threads": T, "cores": os.cpu_count(),
-                      "iterations_per_thread": n_iter, "spp": T * n_iter, "seconds": secs, "s_per_iteration": secs / n_iter,
-                      "samples_per_s": T * n_iter * w * h / secs, "extend_mrays_per_s": rs["extend_rays"] / secs / 1e6,
-                      "shadow_mrays_per_s": rs["shadow_rays"] / secs / 1e6}
+        if ref is not None:
+            _, secs, rs = ref.render(w, h, threads=T, iterations_per_thread=n_iter, mode=0, seed=1, stats=True)
+            row["cpu"] = {"kind": "port (oracle, C++ restatement, -O2 -ffp-contract=off)", "threads": T, "cores": os.cpu_count(),
+                          "iterations_per_thread": n_iter, "spp": T * n_iter, "seconds": secs, "s_per_iteration": secs / n_iter,
+                          "samples_per_s": T * n_iter * w * h / secs, "extend_mrays_per_s": rs["extend_rays"] / secs / 1e6,
+                          "shadow_mrays_per_s": rs["shadow_rays"] / secs / 1e6}
         if not args.no_gpu:
             dev = scene.upload(flags=pt.FLAG_TIME_KERNELS)
             ph = scene.pinhole(w, h)
             buf = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
             stream = torch.cuda.current_stream().cuda_stream
-            dev.render_device(ph, min(gpu_spp, 64), buf.data_ptr(), seed=0, first_sample=0, stream=stream)  # warm-up: allocations
+            # warm-up with the call that is timed: the queues get their final size, and memory that an earlier handle of
+            # this process gave back is handed out again (the driver scrubs it first: ~1.4 s per 127 GB, measured with
+            # tools/call_sequence_probe.py) before the clock starts
+            dev.render_device(ph, gpu_spp, buf.data_ptr(), seed=0, first_sample=0, stream=stream)
             torch.cuda.synchronize()
             dev.stats_reset()
             t0 = time.perf_counter()
@@ -65,7 +70,8 @@ def main():
                           "extend_mrays_per_s": g["extend_rays"] / g["extend_ms"] / 1e3, "shadow_mrays_per_s": g["shadow_rays"] / g["shadow_ms"] / 1e3 if g["shadow_ms"] else None,
                           "extend_rays_per_sample": g["extend_rays"] / (gpu_spp * w * h), "shadow_rays_per_sample": g["shadow_rays"] / (gpu_spp * w * h),
                           "queue_bytes": dev.memory()}
-            row["gpu_over_cpu"] = row["gpu"]["samples_per_s"] / row["cpu"]["samples_per_s"]
+            if "cpu" in row:
+                row["gpu_over_cpu"] = row["gpu"]["samples_per_s"] / row["cpu"]["samples_per_s"]
             dev.close()
             del buf
         print(json.dumps(row), flush=True)
