@@ -254,7 +254,7 @@ int ptx_intersect_batch_device(ptx_scene* scene, const ptx_ray* d_rays, size_t n
                                void* stream);
 /* ptx_intersect_batch_device for callers that cannot allocate (HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same kernel and same results; the work
- * cursor and the stack-spill area live in a file-scope device array of the library (17.0 MiB per GPU, held
+ * cursor and the stack-spill area live in a file-scope device array of the library (34.0 MiB per GPU, held
  * until the process ends) instead of scene-owned allocations, and the call creates no event and takes no
  * timing stamp: it enqueues one 4-byte memset and one kernel on `stream`.  At most PTX_NOALLOC_MAX_RAYS rays
  * per call (PTX_E_LIMIT beyond).  All handles on one GPU share that array: calls that overlap on one GPU

@@ -213,13 +213,13 @@ __device__ inline void wave_add(unsigned long long* dst, uint32_t v) {
 //     spill area beyond that (the reference allows 25 levels, kdtree/src/lib.rs:16).
 // Decisions per ray are exactly those of kd_traverse() in traverse.hpp (= KdNode::intersect).
 #ifndef PTX_TBLOCK
-#define PTX_TBLOCK 512
+#define PTX_TBLOCK 1024  // 16 waves: two workgroups fill a CU, so the LDS copy of the tree top is held twice, not four times
 #endif
 #ifndef PTX_LDS_DEPTH
 #define PTX_LDS_DEPTH 8
 #endif
 #ifndef PTX_TOP_NODES
-#define PTX_TOP_NODES 255
+#define PTX_TOP_NODES 511  // 8 KB; 512-thread workgroups have room for 255 beside 8 stack levels (profiles/r02_loop_variants.txt)
 #endif
 #ifndef PTX_REFILL_IDLE
 #define PTX_REFILL_IDLE 16
@@ -231,7 +231,7 @@ __device__ inline void wave_add(unsigned long long* dst, uint32_t v) {
 #define PTX_TRI_BATCH_ANY 16
 #endif
 #ifndef PTX_BLOCKS_PER_CU
-#define PTX_BLOCKS_PER_CU 4
+#define PTX_BLOCKS_PER_CU 2
 #endif
 constexpr int TBLOCK = PTX_TBLOCK;        // threads per traversal workgroup
 constexpr int LDS_DEPTH = PTX_LDS_DEPTH;  // stack levels kept in LDS
@@ -250,7 +250,7 @@ constexpr uint32_t TRI_BATCH_ANYHIT = PTX_TRI_BATCH_ANY;
 #define PTX_SHADE_WAVES 1  // minimum waves per SIMD the register allocation of k_shade must allow
 #endif
 #ifndef PTX_ROUNDS
-#define PTX_ROUNDS 2  // (node steps, exit step) rounds per loop iteration before the triangle step is considered
+#define PTX_ROUNDS 3  // (node steps, exit step) rounds per loop iteration before the triangle step is considered
 #endif
 #ifndef PTX_FORCE_LOBE
 #define PTX_FORCE_LOBE 0
@@ -326,7 +326,7 @@ __device__ __forceinline__ void st_stream(uint8_t* p, uint8_t v) {
 // array's name as an address: ptx_scene_create asks hipGetSymbolAddress once per device and keeps the pointer.
 constexpr int NOALLOC_GRID = 256;  // workgroups of the allocation-free launch (one per CU)
 constexpr size_t NOALLOC_SPILL_BYTES = (size_t)(PTX_MAX_DEPTH - LDS_DEPTH) * NOALLOC_GRID * TBLOCK * sizeof(uint2);
-constexpr size_t NOALLOC_SCRATCH_BYTES = 256 + NOALLOC_SPILL_BYTES;  // 17.0 MiB
+constexpr size_t NOALLOC_SCRATCH_BYTES = 256 + NOALLOC_SPILL_BYTES;  // 34.0 MiB
 static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
 
 struct TravArgs {
