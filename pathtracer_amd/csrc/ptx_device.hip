@@ -219,7 +219,7 @@ __device__ inline void wave_add(unsigned long long* dst, uint32_t v) {
 #define PTX_LDS_DEPTH 8
 #endif
 #ifndef PTX_TOP_NODES
-#define PTX_TOP_NODES 511  // 8 KB; 512-thread workgroups have room for 255 beside 8 stack levels (profiles/r02_loop_variants.txt)
+#define PTX_TOP_NODES 1023  // 16 KB beside the 64 KB ring of a 1024-thread workgroup: two workgroups fill the 160 KB of a CU
 #endif
 #ifndef PTX_REFILL_IDLE
 #define PTX_REFILL_IDLE 16
@@ -351,20 +351,32 @@ struct TravArgs {
     unsigned long long* prof;  // [12] loop profile (COUNT): see ptx_debug_loop_profile
 };
 
-// Leaving a leaf (kdtree/src/lib.rs:95-103).  The pop is read unconditionally (LDS offsets clamped into the column; for
-// an empty stack the "top" is the sentinel and the values go unused) and selected afterwards; the spill area is a rare
+// Leaving a leaf (kdtree/src/lib.rs:95-103).  The two newest entries are read unconditionally from the ring (for an
+// empty stack the values go unused) and selected afterwards; entries that were evicted to global memory are a rare
 // branch on top.  A finished lane keeps its answer in registers until the next refill writes it out.
+#ifdef PTX_SPILL_PROBE  // probe build: the "refills" / "live_lanes" slots of the loop profile count evictions / reloads
+#define PTX_COUNT_SPILL_POP if (COUNT) ++pf_live;
+#define PTX_COUNT_SPILL_PUSH if (COUNT) ++pf_refill;
+#else
+#define PTX_COUNT_SPILL_POP
+#define PTX_COUNT_SPILL_PUSH
+#endif
 #define PTX_EXIT_STEP \
             if (COUNT && __any(cur == DESC_EXIT)) pf_end_iter += lane == 0 ? 1u : 0u; \
             if (cur == DESC_EXIT) { \
                 if (COUNT) ++pf_end; \
                 const uint32_t st = so - LVL; \
                 const uint32_t sb = st - LVL; \
-                uint2 top = PTX_SLOT(st < so_last ? st : so_last); \
-                uint32_t tb = PTX_SLOT(sb < so_last ? sb : so_last).y; \
-                if (st > so_last) { \
-                    top = PTX_SPILL(st); \
-                    if (sb > so_last) tb = PTX_SPILL(sb).y; \
+                uint2 top = PTX_SLOT(st); \
+                uint32_t tb = PTX_SLOT(sb).y; \
+                tb = sb == so0 ? f2u(t_end) : tb; \
+                if (sb <= ev && ev != so0) { \
+                    if (st <= ev) { \
+                        top = PTX_SPILL(st); \
+                        ev = sb; \
+                        PTX_COUNT_SPILL_POP \
+                    } \
+                    if (sb != so0) tb = PTX_SPILL(sb).y; \
                 } \
                 const bool done = bi != PTX_MISS || t2 == t_end || st == so0; \
                 cur = done ? DESC_IDLE : (int32_t)top.x; \
@@ -374,17 +386,23 @@ struct TravArgs {
             }
 template <bool ANY, bool COUNT>
 __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
-    // Level 0 of a lane's stack column is a sentinel {-, t_end}: the entry "below" the first real entry, so a
-    // pop needs no special case for the segment end of an emptied stack.  Stack positions are kept as LDS
-    // byte offsets (one add per push/pop, no address arithmetic).
-    __shared__ uint2 s_stack[LDS_DEPTH + 1][TBLOCK];
+    // The traversal stack of a lane is a ring of LDS_DEPTH entries in LDS that always holds the NEWEST levels: when
+    // a push finds the ring full, the oldest level it holds moves to the lane's column of a.spill (a store, off the
+    // critical path), and a pop only reads global memory once the ring has run empty while older levels remain -
+    // rare, because a ray that finds its hit never comes back for them.  (Spilling the newest levels instead put a
+    // dependent global load into 0.27 of the wave iterations of the extend kernel on cornell_teapot and 0.87 of the
+    // shadow kernel's on sr2: tools/spill_probe.py.)  Stack positions are LOGICAL byte offsets, off(level) = so0 +
+    // LVL * level, kept so that the ring slot of a level is off & (RING - 1): one AND per access.  Level 0 is "below
+    // the first entry": its t is the ray's t_end, taken from the register.
+    static_assert((LDS_DEPTH & (LDS_DEPTH - 1)) == 0 && (TBLOCK & (TBLOCK - 1)) == 0, "the ring needs powers of two");
+    __shared__ uint2 s_stack[LDS_DEPTH][TBLOCK];
     __shared__ uint4 s_top[TOP_NODES > 0 ? TOP_NODES : 1];
     char* const s_base = reinterpret_cast<char*>(&s_stack[0][0]);
-    constexpr uint32_t LVL = TBLOCK * 8u;  // bytes per stack level
+    constexpr uint32_t LVL = TBLOCK * 8u;        // bytes per stack level
+    constexpr uint32_t RING = LVL * LDS_DEPTH;   // bytes of the ring
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t gtid = blockIdx.x * TBLOCK + tid;
-    const uint32_t so0 = tid * 8u;                    // this lane's sentinel
-    const uint32_t so_last = so0 + LVL * LDS_DEPTH;   // its last LDS level; deeper levels live in a.spill
+    const uint32_t so0 = RING - LVL + tid * 8u;  // off(0): level 1 lands in ring slot 0 of this lane's column
     const bool segmented = a.seg_counts != nullptr;
     const uint32_t n_seg = segmented ? a.n_seg : 1u;
     const uint32_t seg_stride = a.seg_cap * a.count_scale;
@@ -425,7 +443,8 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, t_end = 0, t1 = 0, t2 = 0;
     constexpr uint32_t NO_RAY = 0xFFFFFFFFu;
     uint32_t ridx = NO_RAY;  // ray whose answer this lane holds or works on
-    uint32_t so = so0 + LVL;  // offset of the next free stack slot; so0 + LVL == empty
+    uint32_t so = so0 + LVL;  // off(level of the next push); so0 + LVL == empty
+    uint32_t ev = so0;        // off(newest level that lives in a.spill); so0 == none
     uint32_t bi = PTX_MISS;
     float bt = 0.0f, bu = 0.0f, bv = 0.0f;  // stay 0 while bi == PTX_MISS
     uint32_t n_inner = 0, n_tris = 0;
@@ -438,11 +457,13 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
         acc += lane == 0 ? (uint32_t)(now - ck) : 0u; \
         ck = now;                                    \
     }
-#define PTX_SLOT(off) (*reinterpret_cast<uint2*>(s_base + (off)))
-#define PTX_SPILL(off) a.spill[(size_t)(((off) - so_last) / LVL - 1u) * a.spill_stride + gtid]
+#define PTX_SLOT(off) (*reinterpret_cast<uint2*>(s_base + ((off) & (RING - 1u))))
+#define PTX_SPILL(off) a.spill[(size_t)(((off) - so0) / LVL - 1u) * a.spill_stride + gtid]
 
     for (;;) {
+#ifndef PTX_SPILL_PROBE
         if (COUNT) pf_refill += lane == 0 ? 1u : 0u;
+#endif
         // ---- write out the answers of the lanes that have finished since the last refill: once per refill
         // with many lanes, instead of inside the stepping loop whenever a single lane finishes
         if (cur == DESC_IDLE && ridx != NO_RAY) {
@@ -508,7 +529,7 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                 dx = rb.x, dy = rb.y, dz = rb.z, t2 = t_end = a.internal ? 3.402823466e+38f : rb.w;
                 cur = a.root;
                 so = so0 + LVL;
-                PTX_SLOT(so0) = make_uint2(0u, f2u(t_end));
+                ev = so0;
                 bi = PTX_MISS;
                 bt = bu = bv = 0.0f;
             }
@@ -519,7 +540,11 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
 
         // ---- step the live lanes until enough of them have finished to make a refill worthwhile
         for (;;) {
+#ifdef PTX_SPILL_PROBE
+            if (COUNT) pf_iter += lane == 0 ? 1u : 0u;
+#else
             if (COUNT) pf_iter += lane == 0 ? 1u : 0u, pf_live += cur != DESC_IDLE ? 1u : 0u;
+#endif
 #pragma unroll
             for (int round = 0; round < PTX_ROUNDS; ++round) {
             if (round > 0) { PTX_EXIT_STEP }  // (the last round's exit step comes after the triangle step)
@@ -551,9 +576,12 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                 uint32_t next = only_far ? far_d : near_d;
                 next = parallel ? (oa <= dist ? nd.z : nd.w) : next;
                 if (push) {
-                    const uint2 e = make_uint2(far_d, f2u(t));
-                    if (so <= so_last) PTX_SLOT(so) = e;
-                    else PTX_SPILL(so) = e;
+                    if (so - ev > RING) {  // the ring is full: its oldest level sits in the slot this push takes
+                        ev += LVL;
+                        PTX_SPILL(ev) = PTX_SLOT(so);
+                        PTX_COUNT_SPILL_PUSH
+                    }
+                    PTX_SLOT(so) = make_uint2(far_d, f2u(t));
                     so += LVL;
                     t2 = t;
                 }

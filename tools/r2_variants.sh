@@ -1,11 +1,11 @@
 #!/bin/bash
-# round-2 experiments on the GPU box: default bench for every variant library.  usage: bash tools/r2_variants.sh <outdir> [reps]
+# round-2 experiments on the GPU box: default bench for every variant library.  usage: [BENCH_ARGS="--scene sr2 --size 3840x2160 --spp-per-step 96"] bash tools/r2_variants.sh <outdir> [reps]
 OUT=$1; mkdir -p $OUT
 V=$PWD/pathtracer_amd/lib/variants
 for rep in $(seq 1 ${2:-2}); do
 for so in $V/libptx_*.so; do
   n=$(basename $so .so); n=${n#libptx_}
-  PTX_LIB=$so timeout -k 10 200 python -u bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-config3 > $OUT/bench_$n.json 2> $OUT/bench_$n.err || { echo "$n FAILED"; tail -3 $OUT/bench_$n.err; exit 1; }
+  PTX_LIB=$so timeout -k 10 200 python -u bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-config3 ${BENCH_ARGS:-} > $OUT/bench_$n.json 2> $OUT/bench_$n.err || { echo "$n FAILED"; tail -3 $OUT/bench_$n.err; exit 1; }
   python3 -c "
 import json
 d=json.load(open('$OUT/bench_$n.json')); k=d['kernel_ms']
