@@ -208,9 +208,9 @@ __device__ inline void wave_add(unsigned long long* dst, uint32_t v) {
 //   * each loop iteration steps all node-walking lanes by one node; the triangle step (three
 //     16-byte loads of one record) only runs when at least TRI_BATCH lanes are waiting for it or no lane can
 //     walk any further; lanes that have left their leaf pop or finish in the same iteration;
-//   * the traversal stack (far child descriptor, t_split) lives in LDS for the first LDS_DEPTH levels
-//     ([level][thread]: ds_write_b64 / ds_read_b64 without bank conflicts) and in a per-thread global
-//     spill area beyond that (the reference allows 25 levels, kdtree/src/lib.rs:16).
+//   * the traversal stack (far child descriptor, t_split): its LDS_DEPTH newest levels live in an LDS ring
+//     ([level][thread]: ds_write_b64 / ds_read_b64 without bank conflicts), older levels in a per-thread global
+//     spill area (the reference allows 25 levels, kdtree/src/lib.rs:16).
 // Decisions per ray are exactly those of kd_traverse() in traverse.hpp (= KdNode::intersect).
 #ifndef PTX_TBLOCK
 #define PTX_TBLOCK 1024  // 16 waves: two workgroups fill a CU, so the LDS copy of the tree top is held twice, not four times
