@@ -106,7 +106,7 @@ def main():
     scene = pt.LoadedScene(obj, max_bounces=args.max_bounces)
     load_s = time.perf_counter() - t0
     flags = 0 if args.no_events else pt.FLAG_TIME_KERNELS
-    dev = scene.upload(flags=flags)
+    dev = scene.upload(flags=flags, device=torch.cuda.current_device())  # this rank's GPU, named explicitly
     if args.batch_samples:
         dev.set_batch_samples(args.batch_samples)
     pinhole = scene.pinhole(W, H)
