@@ -365,12 +365,21 @@ int ptx_raylog_enable(ptx_scene* scene, uint64_t max_records);
 int ptx_raylog_read(ptx_scene* scene, uint8_t* out, uint64_t cap_records, uint64_t* n_written, uint64_t* n_dropped);
 /* Diagnostic (scenes created with PTX_FLAG_COUNT_WORK; no counterpart in the reference): how the lanes of
  * the traversal kernels spent their loop iterations since the last reset.  out24[0..11] = extend,
- * out24[12..23] = shadow: wave iterations (one iteration = 2 rounds of 2 node steps + a leaf-exit step, then
+ * out24[12..23] = shadow: wave iterations (one iteration = 3 rounds of 2 node steps + a leaf-exit step, then
  * up to 2 triangles per waiting lane), lane-visits of the node steps, wave iterations that ran the
  * triangle step, lane-visits of it, wave iterations that ran the leaf-exit step, lane-visits of it,
  * refill rounds, live lane-iterations, then the wave clock (s_memtime ticks, summed over waves) spent in the
  * refill, node, triangle and leaf-exit parts of the loop. */
 int ptx_debug_loop_profile(ptx_scene* scene, uint64_t* out24);
+/* Test hook (host only, no GPU call): the device layout ptx_scene_create derives from a flattened tree - 16-byte inner
+ * nodes {bits of the plane distance, axis, descriptor of the left child, of the right child}, a descriptor being an
+ * inner-node index (>= 0), 0x80000000 | offset of the leaf's first record, or -1 for an empty leaf; and the leaf
+ * records to lay down, as triangle index | last-of-run << 31, where leaves with equal lists, and lists that are
+ * the tail of a longer one, share a run.  `node_words` (4 per inner node, capacity 4 * n_nodes) and `records`
+ * (capacity n_leaf_indices) may be NULL; counts = {inner nodes, records, root descriptor, nodes of the
+ * breadth-first prefix that the kernels keep in LDS (at most top_nodes)}.  No counterpart in the reference. */
+int ptx_debug_device_tree(const ptx_kdnode* nodes, uint32_t n_nodes, const uint32_t* leaf_indices, uint32_t n_leaf_indices,
+                          uint32_t n_triangles, uint32_t top_nodes, uint32_t* node_words, uint32_t* records, uint32_t counts[4]);
 
 #ifdef __cplusplus
 }

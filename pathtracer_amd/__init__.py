@@ -170,6 +170,17 @@ class KdTree:
         """Intersect-only device scene (the accel seam without shading data)."""
         return DeviceScene.from_arrays(self.triangles, self.nodes, self.leaf_indices, flags=flags)
 
+    def device_layout(self, top_nodes=1023):
+        """What `upload()` lays down for the kernels (host computation, no GPU): (inner nodes as an (n, 4) uint32 array
+        {plane bits, axis, left descriptor, right descriptor}, leaf records as triangle index | last-of-run << 31, root
+        descriptor, size of the breadth-first prefix kept in LDS)."""
+        words = np.zeros((max(len(self.nodes), 1), 4), np.uint32)
+        records = np.zeros(max(len(self.leaf_indices), 1), np.uint32)
+        counts = (C.c_uint32 * 4)()
+        _check(lib().ptx_debug_device_tree(_ptr(self.nodes), len(self.nodes), _ptr(self.leaf_indices), len(self.leaf_indices),
+                                          len(self.triangles), int(top_nodes), _ptr(words), _ptr(records), counts))
+        return words[:counts[0]].copy(), records[:counts[1]].copy(), int(np.int32(np.uint32(counts[2]))), int(counts[3])
+
     def _text(self, fn, *head):
         out, n = C.c_void_p(), C.c_size_t()
         _check(fn(*head, _ptr(self.nodes), len(self.nodes), _ptr(self.leaf_indices), len(self.leaf_indices), C.byref(out), C.byref(n)))

@@ -30,6 +30,7 @@
 #include "../../include/ptx_sampling.h"
 #include "host_internal.hpp"
 #include "device_internal.hpp"
+#include "device_tree.hpp"
 #include "traverse.hpp"
 
 using namespace ptx;
@@ -265,9 +266,6 @@ constexpr uint32_t TRI_BATCH_ANYHIT = PTX_TRI_BATCH_ANY;
 #define PTX_XCD_WINDOWS 0
 #endif
 constexpr int CURSOR_WORDS = 8;  // one work cursor per XCD (PTX_XCD_WINDOWS), else only the first is used
-constexpr int32_t DESC_EXIT = -1, DESC_IDLE = -2;
-constexpr uint32_t DESC_LEAF = 0x80000000u, DESC_PAYLOAD = 0x3FFFFFFFu;
-constexpr uint32_t DESC_MAX_PAYLOAD = 0x3FFFFFFDu;  // offsets and triangle indices stay below 2^30 - 2
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1549,106 +1547,6 @@ int check_scene(ptx_scene* sc, const char* who) {
     return PTX_OK;
 }
 
-// Re-index the ABI's preorder tree into the device layout described above k_traverse.  Returns an empty
-// string, or why the tree does not fit the descriptor fields.
-std::string build_device_tree(const ptx_kdnode* in, uint32_t n_nodes, const uint32_t* leaf_idx, std::vector<uint4>& nodes,
-                              std::vector<uint32_t>& list, int32_t& root, uint32_t& top_n) {
-    top_n = 0;
-    list.clear();
-    auto is_leaf = [&](uint32_t i) { return (in[i].w1 & 3u) == 3u; };
-    bool too_big = false;
-    // Leaves with the same ordered triangle list share ONE run of `list` (and so of leaf_tris), and a list that is
-    // the tail of a longer one points into that run - the "last of the leaf" flag sits on the run's last entry
-    // either way.  The reference's trees repeat themselves a lot (cornell_teapot: 239 012 references in 139 958
-    // non-empty leaves, 48 890 distinct lists), so the records the traversal gathers from shrink by more than half
-    // and more of them stay in the L2.  Which triangles a leaf tests, and in which order, is unchanged.
-    std::unordered_map<std::string, uint32_t> run_of;  // bytes of a list (or of the tail of a stored run) -> offset
-    {
-        auto key_of = [&](const uint32_t* p, uint32_t n) { return std::string(reinterpret_cast<const char*>(p), (size_t)n * 4u); };
-        // which lists need a run of their own: taken longest first, a list that is already the tail of a longer one
-        // does not.  The runs are then laid down in the tree's own (depth-first) order, so that the records of
-        // neighbouring leaves stay near each other.
-        std::vector<uint32_t> leaves;
-        for (uint32_t i = 0; i < n_nodes; ++i)
-            if (is_leaf(i) && (in[i].w1 >> 2) != 0) leaves.push_back(i);
-        std::vector<uint32_t> by_length(leaves);
-        std::stable_sort(by_length.begin(), by_length.end(), [&](uint32_t a, uint32_t b) { return (in[a].w1 >> 2) > (in[b].w1 >> 2); });
-        std::unordered_map<std::string, bool> seen;  // list or tail of a list -> it is a list with a run of its own
-        for (uint32_t src : by_length) {
-            const uint32_t cnt = in[src].w1 >> 2, off = in[src].w0;
-            if (seen.count(key_of(leaf_idx + off, cnt))) continue;
-            seen[key_of(leaf_idx + off, cnt)] = true;
-            for (uint32_t k = 1; k < cnt; ++k) seen.emplace(key_of(leaf_idx + off + k, cnt - k), false);
-        }
-        for (uint32_t src : leaves) {
-            const uint32_t cnt = in[src].w1 >> 2, off = in[src].w0;
-            const auto own = seen.find(key_of(leaf_idx + off, cnt));
-            if (own == seen.end() || !own->second || run_of.count(own->first)) continue;
-            const size_t at = list.size();
-            if (at + cnt > DESC_MAX_PAYLOAD) {
-                too_big = true;
-                break;
-            }
-            for (uint32_t k = 0; k < cnt; ++k) {
-                if (leaf_idx[off + k] > DESC_MAX_PAYLOAD) too_big = true;
-                list.push_back(leaf_idx[off + k] & DESC_PAYLOAD);
-            }
-            list.back() |= 0x80000000u;
-            for (uint32_t k = 0; k < cnt; ++k) run_of.emplace(key_of(leaf_idx + off + k, cnt - k), (uint32_t)(at + k));
-        }
-    }
-    auto leaf_desc = [&](uint32_t src) -> uint32_t {
-        const uint32_t cnt = in[src].w1 >> 2, off = in[src].w0;
-        if (cnt == 0) return (uint32_t)DESC_EXIT;
-        const auto it = run_of.find(std::string(reinterpret_cast<const char*>(leaf_idx + off), (size_t)cnt * 4u));
-        if (it == run_of.end()) return (uint32_t)DESC_EXIT;  // only after too_big
-        return DESC_LEAF | it->second;
-    };
-    nodes.clear();
-    if (is_leaf(0)) {
-        root = (int32_t)leaf_desc(0);
-        return too_big ? "triangle index or leaf list beyond 2^30 - 3" : "";
-    }
-    uint32_t n_inner = 0;
-    for (uint32_t i = 0; i < n_nodes; ++i) n_inner += is_leaf(i) ? 0u : 1u;
-    nodes.assign(n_inner, make_uint4(0u, 0u, (uint32_t)DESC_EXIT, (uint32_t)DESC_EXIT));
-    root = 0;
-    uint32_t used = 1;
-    auto emit = [&](uint32_t src, uint32_t dst, std::vector<std::pair<uint32_t, uint32_t>>& out, bool left_last) {
-        const uint32_t l = src + 1u, r = in[src].w1 >> 2;
-        const bool ll = is_leaf(l), rl = is_leaf(r);
-        const uint32_t dl = ll ? 0u : used++, dr = rl ? 0u : used++;  // inner siblings adjacent
-        const uint32_t desc_l = ll ? leaf_desc(l) : dl, desc_r = rl ? leaf_desc(r) : dr;
-        nodes[dst] = make_uint4(in[src].w0, in[src].w1 & 3u, desc_l, desc_r);
-        if (left_last) {  // for a LIFO: right pushed first so that the left subtree is numbered first
-            if (!rl) out.push_back({r, dr});
-            if (!ll) out.push_back({l, dl});
-        } else {
-            if (!ll) out.push_back({l, dl});
-            if (!rl) out.push_back({r, dr});
-        }
-    };
-    // breadth-first while the node being emitted is inside the LDS prefix ...
-    std::vector<std::pair<uint32_t, uint32_t>> queue{{0u, 0u}};
-    size_t head = 0;
-    while (head < queue.size() && queue[head].second < (uint32_t)TOP_NODES) {
-        const auto e = queue[head++];
-        emit(e.first, e.second, queue, false);
-    }
-    top_n = used < (uint32_t)TOP_NODES ? used : (uint32_t)TOP_NODES;
-    if (top_n > n_inner) top_n = n_inner;
-    // ... depth-first below it (every pending node roots a contiguous subtree)
-    for (; head < queue.size(); ++head) {
-        std::vector<std::pair<uint32_t, uint32_t>> stack{queue[head]};
-        while (!stack.empty()) {
-            const auto e = stack.back();
-            stack.pop_back();
-            emit(e.first, e.second, stack, true);
-        }
-    }
-    return too_big ? "triangle index or leaf list beyond 2^30 - 3" : "";
-}
-
 struct SegRange {  // a segmented queue as the traversal kernel sees it (see RenderState)
     const uint32_t* counts = nullptr;
     const uint32_t* max_ptr = nullptr;
@@ -1807,11 +1705,12 @@ int ptx_scene_create(const ptx_scene_desc* d, uint32_t flags, ptx_scene** out) {
     pack_triangles(d->triangles, d->n_triangles, recs);
     HIP_TRY(sc->nodes.upload(d->nodes, d->n_nodes));
     {
-        std::vector<uint4> dn;
+        std::vector<DevNode> dn;
         std::vector<uint32_t> dl;
-        const std::string big = build_device_tree(d->nodes, d->n_nodes, d->leaf_indices, dn, dl, sc->root_desc, sc->top_n);
+        const std::string big = build_device_tree(d->nodes, d->n_nodes, d->leaf_indices, (uint32_t)TOP_NODES, dn, dl, sc->root_desc, sc->top_n);
         if (!big.empty()) return fail(PTX_E_LIMIT, "ptx_scene_create: " + big);
-        HIP_TRY(sc->dev_nodes.upload(dn.data(), dn.size()));
+        static_assert(sizeof(DevNode) == sizeof(uint4), "a device node is one dwordx4");
+        HIP_TRY(sc->dev_nodes.upload(reinterpret_cast<const uint4*>(dn.data()), dn.size()));
         if (getenv("PTX_VERBOSE"))
             fprintf(stderr, "[ptx] device tree: %zu inner nodes, %zu leaf records for %u leaf references\n", dn.size(), dl.size(), d->n_leaf_indices);
         std::vector<TriRec> lt(dl.size());  // the records in leaf order, tagged with index and last flag

@@ -349,3 +349,66 @@ def test_parallel_obj_parse_equals_the_serial_pass(tmp_path):
     with pytest.raises(pt.PtxError) as e:
         pt.LoadedScene(str(obj))
     assert "usemtl" in str(e.value)
+
+
+def _walk_device_tree(kd, words, records, root):
+    """Walks the ABI tree and the device tree side by side; returns the number of leaves compared."""
+    nodes = np.asarray(kd.nodes).view(np.uint32).reshape(-1, 2)
+    leaf_idx = np.asarray(kd.leaf_indices)
+    stack, leaves = [(0, root)], 0
+    while stack:
+        src, desc = stack.pop()
+        w0, w1 = int(nodes[src, 0]), int(nodes[src, 1])
+        if w1 & 3 == 3:  # leaf: the descriptor names a run that reproduces the list, in order, flagged on its last record
+            want = [int(x) for x in leaf_idx[w0:w0 + (w1 >> 2)]]
+            if not want:
+                assert desc == -1
+            else:
+                assert desc < -2
+                off = desc & 0x3FFFFFFF
+                got = [int(r) for r in records[off:off + len(want)]]
+                assert [g & 0x3FFFFFFF for g in got] == want
+                assert [g >> 31 for g in got] == [0] * (len(want) - 1) + [1]
+            leaves += 1
+            continue
+        assert desc >= 0
+        x, y, z, w = (int(v) for v in words[desc])
+        assert x == w0 and y == (w1 & 3)
+        to_i32 = lambda v: v - (1 << 32) if v & 0x80000000 else v
+        stack.append((w1 >> 2, to_i32(w)))
+        stack.append((src + 1, to_i32(z)))
+    return leaves
+
+
+@pytest.mark.parametrize("name", ["cornell", "cornell_teapot", "sr2"])
+def test_device_tree_layout(name):
+    """The layout ptx_scene_create hands to the kernels (host_devtree.cpp) is the same tree: every inner node keeps its
+    plane and axis, every leaf its triangles in order; equal lists and tails share record runs; the LDS prefix is
+    breadth-first and closed under 'parent of'."""
+    scene = pt.LoadedScene(os.path.join(SCENES, name + ".obj"))
+    kd = scene.kdtree()
+    words, records, root, top_n = kd.device_layout(top_nodes=1023)
+    nodes = np.asarray(kd.nodes).view(np.uint32).reshape(-1, 2)
+    n_leaves = int(((nodes[:, 1] & 3) == 3).sum())
+    assert len(words) == len(nodes) - n_leaves
+    assert _walk_device_tree(kd, words, records, root) == n_leaves
+    # prefix: nodes [0, top_n) are reached from the root without leaving the prefix, and top_n is as large as allowed
+    assert top_n == min(1023, len(words))
+    inner_children = [int(c) for c in words[:top_n, 2:4].ravel() if int(c) < 0x80000000]
+    assert set(range(1, top_n)) <= set(inner_children)
+    # sharing: never more records than references, and far fewer on the big trees
+    assert len(records) <= len(kd.leaf_indices)
+    if name != "cornell":
+        assert len(records) < 0.55 * len(kd.leaf_indices)
+    # a different prefix size gives the same tree
+    w2, r2, root2, top2 = kd.device_layout(top_nodes=255)
+    assert top2 == min(255, len(w2)) and _walk_device_tree(kd, w2, r2, root2) == n_leaves
+    assert np.array_equal(r2, records)
+
+
+def test_device_tree_rejects_malformed():
+    scene = pt.LoadedScene(os.path.join(SCENES, "cornell.obj"))
+    kd = scene.kdtree()
+    bad = pt.KdTree(kd.triangles, kd.nodes.copy(), kd.leaf_indices[:-1])
+    with pytest.raises(pt.PtxError):
+        bad.device_layout()

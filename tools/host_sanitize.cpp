@@ -25,6 +25,13 @@ int main(int argc, char** argv) {
         if (nn != d.n_nodes || memcmp(nodes, d.nodes, nn * 8) || nt != d.n_triangles) return 4;
         ptx_tree_stats st; ptx_kdtree_stats(d.triangles, d.n_triangles, d.nodes, d.n_nodes, d.leaf_indices, d.n_leaf_indices, nullptr, &st);
         char* pretty = nullptr; size_t pl = 0; ptx_kdtree_write_pretty(d.nodes, d.n_nodes, d.leaf_indices, d.n_leaf_indices, &pretty, &pl);
+        // the device layout of the tree (host_devtree.cpp): shared record runs, breadth-first prefix
+        {
+            std::vector<uint32_t> words(4 * (size_t)d.n_nodes), recs(d.n_leaf_indices + 1);
+            uint32_t counts[4];
+            if (ptx_debug_device_tree(d.nodes, d.n_nodes, d.leaf_indices, d.n_leaf_indices, d.n_triangles, 1023, words.data(), recs.data(), counts)) return 7;
+            if (counts[1] > d.n_leaf_indices) return 8;
+        }
         // rays through the host traversal
         unsigned seed = 1; int hits = 0;
         for (int i = 0; i < 2000; ++i) {
