@@ -188,15 +188,21 @@ def main():
             out["kernel_ms"] = {"extend": ext_ms, "shadow": sh_ms, "shade": st["shade_ms"], "generate": st["generate_ms"], "resolve_accumulate": st["other_ms"]}
             # algorithmic bytes per extend ray: 32 ray + 16 hit + 8 per inner node + 40 per triangle test,
             # node/triangle counts measured on this workload by a counting pass outside the timed region
-            cdev = scene.upload(flags=pt.FLAG_COUNT_WORK)
+            # The counts are those of the REFERENCE algorithm (FLAG_NO_BOX_CLIP: every ray walked over its whole range, equal
+            # to the CPU oracle's counters, tests/test_gpu_parity.py), as SURVEY 8d defines B_ray; the product kernels narrow
+            # every ray to the bounding box of the triangles and visit fewer nodes for the same hits: "visited" below.
             tmp = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
-            cdev.render_device(pinhole, min(spp, 4), tmp.data_ptr(), seed=0, first_sample=base_sample, stream=stream)
-            torch.cuda.synchronize()
-            c = cdev.stats()
-            cdev.close()
-            nodes_per_ray = c["extend_inner_nodes"] / max(c["extend_rays"], 1)
-            tris_per_ray = c["extend_tri_tests"] / max(c["extend_rays"], 1)
+            counted = {}
+            for label, fl in (("reference", pt.FLAG_COUNT_WORK | pt.FLAG_NO_BOX_CLIP), ("visited", pt.FLAG_COUNT_WORK)):
+                cdev = scene.upload(flags=fl, device=torch.cuda.current_device())
+                cdev.render_device(pinhole, min(spp, 4), tmp.data_ptr(), seed=0, first_sample=base_sample, stream=stream)
+                torch.cuda.synchronize()
+                c = cdev.stats()
+                cdev.close()
+                counted[label] = (c["extend_inner_nodes"] / max(c["extend_rays"], 1), c["extend_tri_tests"] / max(c["extend_rays"], 1))
+            nodes_per_ray, tris_per_ray = counted["reference"]
             b_ray = 48.0 + 8.0 * nodes_per_ray + 40.0 * tris_per_ray
+            b_ray_visited = 48.0 + 8.0 * counted["visited"][0] + 40.0 * counted["visited"][1]
             launches = st["extend_launches"]
             achieved = st["extend_rays"] * b_ray / (ext_ms * 1e-3) / 1e9
             # with several sample batches in flight (ptx_set_pipelines > 1; the default is 1) launches of different
@@ -231,6 +237,10 @@ def main():
                 "hbm_measured": {"bytes_per_ray": hbm_per_ray, "GBps": hbm_per_ray * rays_per_s / 1e9,
                                  "frac": hbm_per_ray * rays_per_s / 1e9 / HBM_PEAK_GBS} if hbm_per_ray else None,
                 "bytes_per_ray": b_ray,
+                "visited": {"note": "what the kernel itself walks after narrowing every ray to the bounding box of the triangles (same hits)",
+                            "inner_nodes_per_ray": counted["visited"][0], "tri_tests_per_ray": counted["visited"][1],
+                            "bytes_per_ray": b_ray_visited, "achieved": st["extend_rays"] * b_ray_visited / (ext_ms * 1e-3) / 1e9,
+                            "frac": st["extend_rays"] * b_ray_visited / (ext_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "inner_nodes_per_ray": nodes_per_ray,
                 "tri_tests_per_ray": tris_per_ray,
                 "launches": launches,

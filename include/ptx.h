@@ -135,6 +135,10 @@ typedef struct ptx_scene ptx_scene; /* opaque: device-resident scene (one GPU) *
 #define PTX_FLAG_MATERIAL_QUEUES 8u /* shade the entries of every queue segment grouped by the material they hit (SURVEY 8f-1;
                                        same images bit for bit; measured slower than queue order, off by default: DESIGN.md 8) */
 
+#define PTX_FLAG_NO_BOX_CLIP 16u /* traverse every ray over its whole [t_min, t_max] as the reference does, instead of only over its
+                                    passage through the (widened) bounding box of the triangles: same hits, more node visits -
+                                    the counting pass that prices the reference algorithm, and the A/B of the tests */
+
 const char* ptx_last_error(void);
 const char* ptx_version(void);
 

@@ -27,6 +27,7 @@ FLAG_COUNT_WORK = 1
 FLAG_TIME_KERNELS = 2
 FLAG_CHECK_BRUTE = 4
 FLAG_MATERIAL_QUEUES = 8
+FLAG_NO_BOX_CLIP = 16
 
 
 class PtxError(RuntimeError):

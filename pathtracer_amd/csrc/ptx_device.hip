@@ -339,6 +339,8 @@ struct TravArgs {
     uint32_t n_seg, seg_cap;
     uint32_t count_scale, fixed_count;
     uint32_t internal;  // rays of the renderer's own extend queue: t in [0, f32::MAX], w fields carry path id / bounce
+    uint32_t clip;      // narrow every ray's t range to the bounding box of the triangles (see the refill)
+    float box_lo[3], box_hi[3];  // that box, widened
     int32_t root;    // descriptor of the root
     ptx_hit* hits;   // nearest-hit output (ANY == false)
     uint8_t* occ;    // occlusion output    (ANY == true)
@@ -526,6 +528,39 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                 ox = ra.x, oy = ra.y, oz = ra.z, t1 = a.internal ? 0.0f : ra.w;
                 dx = rb.x, dy = rb.y, dz = rb.z, t2 = t_end = a.internal ? 3.402823466e+38f : rb.w;
                 cur = a.root;
+                if (a.clip && t1 <= t_end) {  // (a window that is empty or NaN is walked as the reference walks it)
+                    // The reference walks the ray's whole range [t_min, t_max] - [0, f32::MAX] for the renderer's rays -
+                    // and so visits, and tests the triangles of, every cell whose split planes the LINE crosses, also
+                    // beyond the point where the ray has left the scene.  A triangle can only be hit inside the
+                    // bounding box of the triangles, so the range is narrowed to the ray's passage through that box:
+                    // the traversal then makes the same decisions on the part of the range that is left (the split
+                    // distances do not change), reaches every leaf whose segment of the ray meets the box, and accepts
+                    // there what the reference accepts.  The box is widened by a thousandth of the scene's extent,
+                    // the slabs by 1e-5 of the ray's distance to them and the range by 1e-4 of itself - four orders
+                    // of magnitude more than the rounding of the reciprocal and of the Moeller-Trumbore t, including
+                    // for a ray that grazes a face of the box, where the widening of the box is divided by the same small
+                    // direction component that amplifies the rounding.  PTX_FLAG_NO_BOX_CLIP walks the full range
+                    // (the counting pass that prices the reference algorithm; tests compare the two hit for hit).
+                    float te = t1, tx = t_end;
+#define PTX_SLAB(o, d, k)                                                         \
+    {                                                                             \
+        const float inv = __builtin_amdgcn_rcpf(d);                               \
+        const float wl = a.box_lo[k] - o, wh = a.box_hi[k] - o;                   \
+        const float pad = 1.0e-5f * fmaxf(fabsf(wl), fabsf(wh));                  \
+        const float ta = (wl - pad) * inv, tb = (wh + pad) * inv;                 \
+        te = fmaxf(te, fminf(ta, tb)); /* a NaN (0 * inf) leaves the bound alone */ \
+        tx = fminf(tx, fmaxf(ta, tb));                                            \
+    }
+                    PTX_SLAB(ox, dx, 0)
+                    PTX_SLAB(oy, dy, 1)
+                    PTX_SLAB(oz, dz, 2)
+#undef PTX_SLAB
+                    te = te - fabsf(te) * 1.0e-4f;
+                    tx = tx + fabsf(tx) * 1.0e-4f;
+                    if (te > t1) t1 = te;
+                    if (tx < t_end) t2 = t_end = tx;
+                    if (!(t1 <= t_end)) cur = DESC_EXIT;  // the ray misses the box: done at the next exit step (empty stack)
+                }
                 so = so0 + LVL;
                 ev = so0;
                 bi = PTX_MISS;
@@ -1300,6 +1335,8 @@ struct ptx_scene {
     DevBuf<TriRec> leaf_tris;   // triangle records in leaf order, index + last flag in f[10] (see k_traverse)
     int32_t root_desc = DESC_EXIT;
     uint32_t top_n = 0;  // inner nodes served from LDS
+    bool clip_box = false;
+    float box_lo[3] = {0, 0, 0}, box_hi[3] = {0, 0, 0};  // bounding box of the triangles, widened
     int tgrid = 1024;  // traversal workgroups (TBLOCK threads each)
     DevBuf<uint32_t> leaf_idx;
     DevBuf<TriRec> tris;
@@ -1570,6 +1607,8 @@ int launch_traverse(ptx_scene* sc, const ptx_ray* d_rays, const SegRange& sr, ui
     a.seg_cap = sr.cap;
     a.count_scale = sr.scale;
     a.internal = sr.internal ? 1u : 0u;
+    a.clip = sc->clip_box ? 1u : 0u;
+    for (int k = 0; k < 3; ++k) a.box_lo[k] = sc->box_lo[k], a.box_hi[k] = sc->box_hi[k];
     a.fixed_count = n;
     a.hits = d_hits;
     a.occ = d_occ;
@@ -1703,6 +1742,18 @@ int ptx_scene_create(const ptx_scene_desc* d, uint32_t flags, ptx_scene** out) {
 
     std::vector<TriRec> recs;
     pack_triangles(d->triangles, d->n_triangles, recs);
+    if (!(flags & PTX_FLAG_NO_BOX_CLIP) && d->n_triangles) {  // bounding box of the triangles for k_traverse's range clip
+        float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+        for (size_t v = 0; v < 3 * (size_t)d->n_triangles; ++v)
+            for (int k = 0; k < 3; ++k) {
+                const float c = d->triangles[3 * v + k];
+                lo[k] = c < lo[k] ? c : lo[k], hi[k] = c > hi[k] ? c : hi[k];
+            }
+        float ext = 0;
+        for (int k = 0; k < 3; ++k) ext = hi[k] - lo[k] > ext ? hi[k] - lo[k] : ext;
+        for (int k = 0; k < 3; ++k) sc->box_lo[k] = lo[k] - 1e-3f * ext - 1e-6f, sc->box_hi[k] = hi[k] + 1e-3f * ext + 1e-6f;
+        sc->clip_box = true;
+    }
     HIP_TRY(sc->nodes.upload(d->nodes, d->n_nodes));
     {
         std::vector<DevNode> dn;

@@ -172,7 +172,8 @@ def test_render_bit_exact_vs_oracle_counter_mode(name, w, h, spp, bounces):
 def test_render_accumulates_into_buffer_and_counts_rays():
     path = os.path.join(SCENES, "cornell.obj")
     scene = pt.LoadedScene(path)
-    dev = scene.upload(flags=pt.FLAG_COUNT_WORK | pt.FLAG_TIME_KERNELS)
+    # FLAG_NO_BOX_CLIP: the reference's own traversal range, so that the node and triangle counts are the oracle's
+    dev = scene.upload(flags=pt.FLAG_COUNT_WORK | pt.FLAG_TIME_KERNELS | pt.FLAG_NO_BOX_CLIP)
     ph = scene.pinhole(32, 32)
     a = dev.render(ph, 2, seed=1)
     b = dev.render(ph, 2, seed=1, first_sample=2, accum=a.copy())
@@ -187,6 +188,13 @@ def test_render_accumulates_into_buffer_and_counts_rays():
     assert s["extend_inner_nodes"] == st["extend_inner_nodes"] and s["extend_tri_tests"] == st["extend_tri_tests"]
     assert s["samples"] == 2 * 32 * 32 and s["extend_ms"] > 0
     dev.close()
+    # the default (ranges narrowed to the bounding box of the triangles): same image, same rays, fewer node visits
+    clip = scene.upload(flags=pt.FLAG_COUNT_WORK)
+    assert clip.render(ph, 2, seed=1).tobytes() == a.tobytes()
+    sc = clip.stats()
+    assert sc["extend_rays"] == s["extend_rays"] and sc["shadow_rays"] == s["shadow_rays"]
+    assert sc["extend_inner_nodes"] < s["extend_inner_nodes"] and sc["extend_tri_tests"] <= s["extend_tri_tests"]
+    clip.close()
 
 
 def test_sample_sharding_is_exact_on_gpu():
@@ -236,3 +244,65 @@ def test_pathtracer_cli_renders_a_png(tmp_path):
     want = pt.to_rgb8(dev.render(scene.pinhole(64, 48), 4, seed=5), 4)
     assert (img == want).all()
     dev.close()
+
+
+@pytest.mark.parametrize("name", ["cornell_teapot", "sr2", "cubesplosion"])
+def test_box_clip_changes_no_hit(name):
+    """k_traverse narrows every ray's range to its passage through the (widened) bounding box of the triangles; with
+    FLAG_NO_BOX_CLIP it walks the reference's whole range.  Both must return the same hit records, bit for bit, for rays
+    of every kind: from inside and from far outside, towards and past the scene, along and on the faces of the box,
+    axis-parallel, with t windows that start or end inside the scene, empty and NaN windows."""
+    import torch
+
+    scene = pt.LoadedScene(os.path.join(SCENES, name + ".obj"))
+    tris = scene.arrays()["triangles"].reshape(-1, 3)
+    lo, hi = tris.min(0), tris.max(0)
+    ext = float((hi - lo).max())
+    rng = np.random.default_rng(12)
+    n = 1 << 19
+    parts_o, parts_d = [], []
+    inside = lo + rng.random((n, 3), dtype=f32) * (hi - lo)
+    sphere = rng.normal(size=(n, 3)).astype(f32)
+    sphere /= np.linalg.norm(sphere, axis=1, keepdims=True)
+    parts_o.append(inside), parts_d.append(sphere)  # from inside, all directions
+    far = ((lo + hi) / 2 + sphere * ext * rng.uniform(1.0, 50.0, (n, 1))).astype(f32)
+    parts_o.append(far), parts_d.append((inside[::-1] - far).astype(f32))  # from outside towards the scene (not normalised)
+    parts_o.append(far), parts_d.append(rng.normal(size=(n, 3)).astype(f32))  # from outside, mostly past it
+    on_face = inside.copy()  # on a face of the box, grazing along it and leaving / entering at small angles
+    axis = rng.integers(0, 3, n)
+    side = rng.integers(0, 2, n)
+    on_face[np.arange(n), axis] = np.where(side == 0, lo[axis], hi[axis])
+    graze = sphere.copy()
+    graze[np.arange(n), axis] *= rng.choice(np.array([0.0, 1e-7, -1e-7, 1e-4, -1e-4, 1.0], f32), n)
+    parts_o.append(on_face), parts_d.append(graze)
+    axial = np.zeros((n, 3), f32)  # axis-parallel, +-0 in the other components
+    axial[np.arange(n), axis] = np.where(side == 0, 1.0, -1.0)
+    axial[np.arange(n), (axis + 1) % 3] = np.where(rng.integers(0, 2, n) == 0, 0.0, -0.0)
+    parts_o.append(np.where(rng.integers(0, 2, (n, 1)) == 0, inside, far).astype(f32)), parts_d.append(axial)
+    o = np.concatenate(parts_o)
+    d = np.concatenate(parts_d)
+    m = len(o)
+    tmin = np.zeros(m, f32)
+    tmax = np.full(m, np.finfo(f32).max, f32)
+    k = rng.integers(0, 8, m)  # windows: [0, 1], [a, b] inside the scene, empty, NaN
+    tmax[k == 1] = 1.0
+    tmin[k == 2] = rng.random(m, dtype=f32)[k == 2] * 0.5
+    tmax[k == 2] = tmin[k == 2] + rng.random(m, dtype=f32)[k == 2] * ext
+    tmin[k == 3], tmax[k == 3] = 2.0, 1.0
+    tmax[k == 4] = np.nan
+    rays = np.zeros(m, pt.RAY_DTYPE)
+    rays["o"], rays["d"], rays["tmin"], rays["tmax"] = o, d, tmin, tmax
+    d_rays = torch.from_numpy(rays.view(np.uint8).reshape(-1)).cuda()
+    out = []
+    for flags in (0, pt.FLAG_NO_BOX_CLIP):
+        dev = scene.kdtree().upload(flags=flags)
+        hits = torch.zeros(m * 16, dtype=torch.uint8, device="cuda")
+        dev.intersect_device(d_rays.data_ptr(), m, hits.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        occ = torch.zeros(m, dtype=torch.uint8, device="cuda")
+        dev.occluded_device(d_rays.data_ptr(), m, occ.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        out.append((hits.cpu().numpy().tobytes(), occ.cpu().numpy().tobytes()))
+        dev.close()
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    h = np.frombuffer(out[0][0], pt.HIT_DTYPE)
+    assert 0.05 < (h["index"] != 0xFFFFFFFF).mean() < 0.95  # the set exercises hits and misses
