@@ -247,6 +247,9 @@ constexpr uint32_t TRI_BATCH_ANYHIT = PTX_TRI_BATCH_ANY;
 #ifndef PTX_TRI_UNROLL
 #define PTX_TRI_UNROLL 2  // triangles per triangle step (1 / 2 / 3: 1.705 / 1.725 / 1.67 G samples/s)
 #endif
+#ifndef PTX_MAX_CHUNK
+#define PTX_MAX_CHUNK 512u
+#endif
 #ifndef PTX_SHADE_WAVES
 #define PTX_SHADE_WAVES 1  // minimum waves per SIMD the register allocation of k_shade must allow
 #endif
@@ -418,8 +421,10 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
     // rounds of 64 rays per wave over the launch) are handed out in windows of 64 after all the large ones, so
     // that the launch does not end with a few waves working through a large window each.
     const uint32_t n_waves = gridDim.x * (TBLOCK / 64);
+    const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (TBLOCK / 64) + (tid >> 6));
     const unsigned long long est = (unsigned long long)max_count * n_seg / (n_waves * 4u);
-    const uint32_t chunk = est >= 512u ? 512u : (est >= 256u ? 256u : (est >= 128u ? 128u : 64u));
+    uint32_t chunk = 64u;  // largest power of two <= est within [64, PTX_MAX_CHUNK]
+    while (chunk < PTX_MAX_CHUNK && 2ull * chunk <= est) chunk *= 2u;
     const uint32_t tail = chunk > 64u ? ((2u * n_waves + n_seg - 1u) / n_seg) * 64u : 0u;  // per segment
     const uint32_t head_max = max_count > tail ? max_count - tail : 0u;
     const uint32_t wps_a = (head_max + chunk - 1u) / chunk;        // large windows per segment
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
     const uint32_t n_windows = n_a + wps_b * n_seg;
 #endif
     uint32_t lo = 0, hi = 0;
-    bool drained = false;  // the launch's cursor has passed the last window
+    uint32_t windows = 0;  // 0: this wave has not taken its own first window yet, 1: it takes windows from the cursor, 2: no window is left
     int32_t cur = DESC_IDLE;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, t_end = 0, t1 = 0, t2 = 0;
     constexpr uint32_t NO_RAY = 0xFFFFFFFFu;
@@ -481,14 +486,14 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
             const unsigned long long idle = __ballot(cur == DESC_IDLE);
             if (!idle) break;
             if (lo >= hi) {
-                if (drained) break;
+                if (windows == 2u) break;
                 uint32_t w = 0;
 #if PTX_XCD_WINDOWS
                 if (lane == 0) w = atomicAdd(a.cursor + xcd, 1u);
                 w = __builtin_amdgcn_readfirstlane(w);
                 if (w >= n_windows) {
                     if (++xcd_tried == 8u) {
-                        drained = true;
+                        windows = 2u;
                         break;
                     }
                     xcd = (xcd + 1u) & 7u;
@@ -499,10 +504,19 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                 const uint32_t seg = wl / per, k = xcd * per + (wl - seg * per);
                 if (k >= (large ? wps_a : wps_b)) continue;  // the last XCDs' eighths may be short
 #else
-                if (lane == 0) w = atomicAdd(a.cursor, 1u);
-                w = __builtin_amdgcn_readfirstlane(w);
+                // the first window of a wave is its own number, the later ones come from the launch's cursor (which
+                // counts from zero: + n_waves); a wave whose own number is past the last window never touches the
+                // cursor - on a small launch that is most of them, and 8192 waves x one device-scope atomic on one
+                // address, ~16 ns each, was the 0.13 ms an empty launch took
+                if (windows == 0u) {
+                    windows = 1u;
+                    w = wave_id;
+                } else {
+                    if (lane == 0) w = atomicAdd(a.cursor, 1u);
+                    w = __builtin_amdgcn_readfirstlane(w) + n_waves;
+                }
                 if (w >= n_windows) {
-                    drained = true;
+                    windows = 2u;
                     break;
                 }
                 const bool large = w < n_a;
@@ -657,7 +671,7 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
             PTX_CLOCK(ck_exit)
             const uint32_t live = (uint32_t)__popcll(__ballot(cur != DESC_IDLE));
             if (live == 0) break;
-            if (!(drained && lo >= hi) && live <= 64u - REFILL_IDLE) break;
+            if (!(windows == 2u && lo >= hi) && live <= 64u - REFILL_IDLE) break;
         }
     }
 #undef PTX_CLOCK
