@@ -247,6 +247,9 @@ constexpr uint32_t TRI_BATCH_ANYHIT = PTX_TRI_BATCH_ANY;
 #ifndef PTX_TRI_UNROLL
 #define PTX_TRI_UNROLL 2  // triangles per triangle step (1 / 2 / 3: 1.705 / 1.725 / 1.67 G samples/s)
 #endif
+#ifndef PTX_TAIL_ROUNDS
+#define PTX_TAIL_ROUNDS 2u  // 64-ray windows per wave handed out after the large ones
+#endif
 #ifndef PTX_MAX_CHUNK
 #define PTX_MAX_CHUNK 512u
 #endif
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
     const unsigned long long est = (unsigned long long)max_count * n_seg / (n_waves * 4u);
     uint32_t chunk = 64u;  // largest power of two <= est within [64, PTX_MAX_CHUNK]
     while (chunk < PTX_MAX_CHUNK && 2ull * chunk <= est) chunk *= 2u;
-    const uint32_t tail = chunk > 64u ? ((2u * n_waves + n_seg - 1u) / n_seg) * 64u : 0u;  // per segment
+    const uint32_t tail = chunk > 64u ? ((PTX_TAIL_ROUNDS * n_waves + n_seg - 1u) / n_seg) * 64u : 0u;  // per segment
     const uint32_t head_max = max_count > tail ? max_count - tail : 0u;
     const uint32_t wps_a = (head_max + chunk - 1u) / chunk;        // large windows per segment
     const uint32_t wps_b = chunk > 64u ? tail / 64u : 0u;          // 64-ray windows per segment
