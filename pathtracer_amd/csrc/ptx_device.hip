@@ -74,10 +74,15 @@ struct RenderState {
     ptx_hit* hits;
     float4* transq[2];  // accumulated transport of the entries of extend queue A / B (travels with the ray)
     Rad* radiance;       // [path id] accumulated radiance of the sample (12 bytes)
-    ptx_ray* sh_rays;    // [i * n_lights + l] shadow ray: origin point_above, direction target - origin, t in [0,1]
+    // Shadow entries of several lights are laid out LIGHT-MAJOR inside a queue segment: the entry of light l of the
+    // segment's k-th shadow record sits at sh_index(seg, l, k) = (seg * n_lights + l) * seg_cap + k, so the rays of a
+    // segment towards ONE light are contiguous and the 64 lanes of a traversal wave aim at one light from neighbouring
+    // surface points (as coherent as camera rays) instead of holding 16 origins x 4 targets.  The traversal launch
+    // sees n_seg * n_lights segments of seg_sh[seg] rays each.  k_resolve folds the lights in MTL order either way.
+    ptx_ray* sh_rays;    // [sh_index] shadow ray: origin point_above, direction target - origin, t in [0,1]
     float4* sh_T;        // [i] {transport before this bounce's update, bits(pid)}
-    float4* sh_contrib;  // [i * n_lights + l] {bsdf * emitted * |cos|, 0}
-    uint8_t* sh_occ;     // [i * n_lights + l] 1 = occluded
+    float4* sh_contrib;  // [sh_index] {bsdf * emitted * |cos|, 0}
+    uint8_t* sh_occ;     // [sh_index] 1 = occluded
     uint8_t* sh_bounce;  // [i] bounce of the path that shot the shadow rays; only while the ray log is on, else null
     uint32_t* perm;      // [slot] PTX_FLAG_MATERIAL_QUEUES: the order in which k_shade takes the entries of a segment (by material of the hit), else null
     // Queues are SEGMENTED: segment s owns slots [s * seg_cap, (s + 1) * seg_cap) of every queue for the
@@ -95,10 +100,9 @@ struct RenderState {
     // Queue entries carry their own path id and bounce number ({o, bits(path id)}, {d, bits(bounce)}).
     uint32_t* seg_next;
     uint32_t seg_range, n_paths;
-    // Totals and per-segment maxima per round, as pairs: [2k] = extend queue of round k+1 (k = 0..rounds),
-    // [2r+1] = shadow queue of round r.  One atomic add + two atomic max per workgroup and kernel.
+    // Totals per round, as pairs: [2k] = extend queue of round k+1 (k = 0..rounds), [2r+1] = shadow queue of round r.
+    // One 64-bit atomic add per workgroup and kernel.
     uint32_t* qcounts;
-    uint32_t* qmax;
     uint32_t* cursors;     // [2 * CURSOR_WORDS * rounds] work cursors of the persistent traversal launches
     unsigned long long* totals;  // extend rays, shadow rays, ext inner, ext tris, sh inner, sh tris
     ptx_pinhole cam;
@@ -268,10 +272,7 @@ constexpr uint32_t TRI_BATCH_ANYHIT = PTX_TRI_BATCH_ANY;
 #ifndef PTX_AUTO_MEMORY_FRACTION
 #define PTX_AUTO_MEMORY_FRACTION 0.5
 #endif
-#ifndef PTX_XCD_WINDOWS
-#define PTX_XCD_WINDOWS 0
-#endif
-constexpr int CURSOR_WORDS = 8;  // one work cursor per XCD (PTX_XCD_WINDOWS), else only the first is used
+constexpr int CURSOR_WORDS = 8;  // a launch's work cursor has 32 bytes to itself (only the first word is used)
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -333,17 +334,122 @@ constexpr size_t NOALLOC_SPILL_BYTES = (size_t)(PTX_MAX_DEPTH - LDS_DEPTH) * NOA
 constexpr size_t NOALLOC_SCRATCH_BYTES = 256 + NOALLOC_SPILL_BYTES;  // 34.0 MiB
 static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
 
+// Windows.  A traversal launch hands its rays out in WINDOWS of one queue segment: `chunk` rays (a power of two in
+// [64, PTX_MAX_CHUNK], about four windows per wave over the launch), all of them first, segment-major, so that
+// neighbouring waves work on neighbouring rays; then the last rays of every segment (together about PTX_TAIL_ROUNDS x 64
+// rays per wave, shared out in proportion to the segments' sizes) in windows of 64, so that the launch does not end
+// with a few waves working through a large window each.  A window costs one atomic on the launch's cursor, and atomics
+// on one address complete ~16 ns apart, so only windows that HOLD rays may exist: the segments of a launch are far
+// from equally full on the open 4K scenes (nine camera rays in ten leave sr2 without a hit; a queue segment is a
+// compact part of the image), and a window grid laid out for the fullest segment - what this kernel used until round 3
+// - made the launch take one atomic per EMPTY window too (sr2 3840x2160: extend -20 %, shadow -15 % time just from
+// 1024-ray instead of 512-ray windows).  k_plan therefore lays the windows of a segmented launch down as two prefix
+// arrays over the segments (large windows, 64-ray windows) and k_traverse finds the segment of window w with a
+// wave-wide 64-ary search (two or three loads of 64 entries).
+struct WinShape {
+    uint32_t chunk, tail_num;  // tail_num / 65536 = share of every segment that goes out in 64-ray windows
+};
+__device__ inline WinShape win_shape(unsigned long long total_rays, uint32_t n_waves) {
+    const unsigned long long est = total_rays / (n_waves * 4ull);
+    WinShape ws{64u, 0u};
+    while (ws.chunk < PTX_MAX_CHUNK && 2ull * ws.chunk <= est) ws.chunk *= 2u;
+    if (ws.chunk > 64u) {
+        const unsigned long long tail_total = (unsigned long long)PTX_TAIL_ROUNDS * n_waves * 64ull;
+        const unsigned long long num = tail_total * 65536ull / total_rays;  // (chunk > 64 implies total_rays > 0)
+        ws.tail_num = num < 65536ull ? (uint32_t)num : 65536u;
+    }
+    return ws;
+}
+// Rays of a segment of `cnt` rays that are handed out in 64-ray windows (the segment's last ones).
+__device__ inline uint32_t win_tail(uint32_t cnt, uint32_t tail_num) {
+    const uint32_t t = ((uint32_t)(((unsigned long long)cnt * tail_num) >> 16) + 63u) & ~63u;
+    return t < cnt ? t : cnt;
+}
+
+constexpr uint32_t PLAN_HEADER = 8;  // words: chunk, large windows, 64-ray windows, tail_num, then the two prefix arrays
+struct PlanArgs {
+    const uint32_t* counts;  // segment s holds counts[s / div] * scale rays
+    uint32_t n_seg, div, scale;
+    uint32_t n_waves;        // waves of the traversal launch the plan is for
+    uint32_t* plan;          // [PLAN_HEADER + 2 * (n_seg + 1)], null = nothing to plan
+};
+
+// One workgroup per plan (a launch plans the shadow queue of round b and the extend queue of round b + 1 together:
+// k_shade(b) wrote both).  Pass 1 sums the rays (-> window size), pass 2 lays the exclusive prefix sums of the
+// segments' window counts down, 1024 segments at a time.
+__global__ __launch_bounds__(1024) void k_plan(PlanArgs p0, PlanArgs p1) {
+    const PlanArgs p = blockIdx.x == 0 ? p0 : p1;
+    if (!p.plan) return;
+    __shared__ unsigned long long s_sum[16];
+    __shared__ uint32_t s_tot[2][16];
+    __shared__ WinShape s_shape;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    unsigned long long sum = 0;
+    for (uint32_t s = tid; s < p.n_seg; s += 1024u) sum += (unsigned long long)p.counts[s / p.div] * p.scale;
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    if (lane == 0) s_sum[wave] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long total = 0;
+        for (int w = 0; w < 16; ++w) total += s_sum[w];
+        s_shape = win_shape(total, p.n_waves);
+        p.plan[0] = s_shape.chunk;
+        p.plan[3] = s_shape.tail_num;
+    }
+    __syncthreads();
+    const WinShape ws = s_shape;
+    uint32_t* const pref_a = p.plan + PLAN_HEADER;
+    uint32_t* const pref_b = pref_a + p.n_seg + 1u;
+    uint32_t carry_a = 0, carry_b = 0;
+    for (uint32_t base = 0; base < p.n_seg; base += 1024u) {
+        const uint32_t s = base + tid;
+        uint32_t wa = 0, wb = 0;
+        if (s < p.n_seg) {
+            const uint32_t cnt = p.counts[s / p.div] * p.scale;
+            const uint32_t tail = win_tail(cnt, ws.tail_num);
+            wa = (cnt - tail + ws.chunk - 1u) / ws.chunk;
+            wb = (tail + 63u) / 64u;
+        }
+        uint32_t ia = wa, ib = wb;  // inclusive scan inside the wave
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t ua = __shfl_up(ia, off), ub = __shfl_up(ib, off);
+            if (lane >= (uint32_t)off) ia += ua, ib += ub;
+        }
+        if (lane == 63u) s_tot[0][wave] = ia, s_tot[1][wave] = ib;
+        __syncthreads();
+        uint32_t before_a = 0, before_b = 0, tile_a = 0, tile_b = 0;
+        for (uint32_t w = 0; w < 16u; ++w) {
+            const uint32_t ta = s_tot[0][w], tb = s_tot[1][w];
+            before_a += w < wave ? ta : 0u, before_b += w < wave ? tb : 0u;
+            tile_a += ta, tile_b += tb;
+        }
+        if (s < p.n_seg) {
+            pref_a[s] = carry_a + before_a + ia - wa;
+            pref_b[s] = carry_b + before_b + ib - wb;
+        }
+        carry_a += tile_a, carry_b += tile_b;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        pref_a[p.n_seg] = carry_a;
+        pref_b[p.n_seg] = carry_b;
+        p.plan[1] = carry_a;
+        p.plan[2] = carry_b;
+    }
+}
+
 struct TravArgs {
     const uint4* nodes;        // inner nodes, device layout
     uint32_t top_n;            // nodes [0, top_n) are copied into LDS by every workgroup (<= TOP_NODES)
     const TriRec* tris;        // leaf_tris: records in leaf order, f[10] = triangle index | last << 31
     const ptx_ray* rays;
     // rays [0, fixed_count), or (seg_counts != NULL) the first seg_counts[s] * count_scale rays of every
-    // segment s, segments seg_cap * count_scale rays apart; *max_ptr = the largest seg_counts[s]
+    // segment s, segments seg_cap * count_scale rays apart
     const uint32_t* seg_counts;
-    const uint32_t* max_ptr;
     uint32_t n_seg, seg_cap;
     uint32_t count_scale, fixed_count;
+    uint32_t seg_div;   // segment s of the launch takes its count from seg_counts[s / seg_div] (light-major shadow queues: n_lights)
+    const uint32_t* plan;  // window plan of a segmented launch (k_plan), else null
     uint32_t internal;  // rays of the renderer's own extend queue: t in [0, f32::MAX], w fields carry path id / bounce
     uint32_t clip;      // narrow every ray's t range to the bounding box of the triangles (see the refill)
     float box_lo[3], box_hi[3];  // that box, widened
@@ -410,41 +516,26 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
     const uint32_t gtid = blockIdx.x * TBLOCK + tid;
     const uint32_t so0 = RING - LVL + tid * 8u;  // off(0): level 1 lands in ring slot 0 of this lane's column
     const bool segmented = a.seg_counts != nullptr;
-    const uint32_t n_seg = segmented ? a.n_seg : 1u;
     const uint32_t seg_stride = a.seg_cap * a.count_scale;
-    const uint32_t max_count = segmented ? *a.max_ptr * a.count_scale : a.fixed_count;  // rays of the fullest segment
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int32_t top_n = (int32_t)a.top_n;
     const uint32_t top_base = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint4*)s_top);
     for (uint32_t i = tid; i < a.top_n; i += TBLOCK) s_top[i] = a.nodes[i];
     __syncthreads();
-    // Windows: `chunk` rays of one segment, ~4 per wave over the launch (64..512).  Every segment gets as many
-    // windows as the fullest one needs (segment-major, so neighbouring waves work on neighbouring rays); the
-    // ones past the end of a shorter segment are skipped.  The last `tail` rays of every segment (about two
-    // rounds of 64 rays per wave over the launch) are handed out in windows of 64 after all the large ones, so
-    // that the launch does not end with a few waves working through a large window each.
+    // Windows (see k_plan): planned for a segmented launch, one segment's arithmetic otherwise.
     const uint32_t n_waves = gridDim.x * (TBLOCK / 64);
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (TBLOCK / 64) + (tid >> 6));
-    const unsigned long long est = (unsigned long long)max_count * n_seg / (n_waves * 4u);
-    uint32_t chunk = 64u;  // largest power of two <= est within [64, PTX_MAX_CHUNK]
-    while (chunk < PTX_MAX_CHUNK && 2ull * chunk <= est) chunk *= 2u;
-    const uint32_t tail = chunk > 64u ? ((PTX_TAIL_ROUNDS * n_waves + n_seg - 1u) / n_seg) * 64u : 0u;  // per segment
-    const uint32_t head_max = max_count > tail ? max_count - tail : 0u;
-    const uint32_t wps_a = (head_max + chunk - 1u) / chunk;        // large windows per segment
-    const uint32_t wps_b = chunk > 64u ? tail / 64u : 0u;          // 64-ray windows per segment
-#if PTX_XCD_WINDOWS
-    // XCD-aware hand-out: each XCD has a cursor of its own over ITS eighth of every segment's windows (a compact
-    // part of the image for the early bounces, so the XCD's L2 sees an eighth of the rays' footprint), and steals
-    // from the next XCD's list when its own is exhausted.
-    const uint32_t per_a = (wps_a + 7u) / 8u, per_b = (wps_b + 7u) / 8u;
-    const uint32_t n_a = per_a * n_seg;
-    const uint32_t n_windows = n_a + per_b * n_seg;  // in one XCD's list
-    uint32_t xcd = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;  // HW_REG_XCC_ID, bits 3:0
-    uint32_t xcd_tried = 0;
-#else
-    const uint32_t n_a = wps_a * n_seg;
-    const uint32_t n_windows = n_a + wps_b * n_seg;
-#endif
+    uint32_t chunk, n_a, n_windows, tail_num;
+    if (segmented) {
+        chunk = a.plan[0], n_a = a.plan[1], n_windows = n_a + a.plan[2], tail_num = a.plan[3];
+    } else {
+        const WinShape ws = win_shape(a.fixed_count, n_waves);
+        const uint32_t tail = win_tail(a.fixed_count, ws.tail_num);
+        chunk = ws.chunk, tail_num = ws.tail_num;
+        n_a = (a.fixed_count - tail + chunk - 1u) / chunk;
+        n_windows = n_a + (tail + 63u) / 64u;
+    }
+    const uint32_t n_pref = a.n_seg + 1u;  // entries of each prefix array of the plan
     uint32_t lo = 0, hi = 0;
     uint32_t windows = 0;  // 0: this wave has not taken its own first window yet, 1: it takes windows from the cursor, 2: no window is left
     int32_t cur = DESC_IDLE;
@@ -491,22 +582,6 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
             if (lo >= hi) {
                 if (windows == 2u) break;
                 uint32_t w = 0;
-#if PTX_XCD_WINDOWS
-                if (lane == 0) w = atomicAdd(a.cursor + xcd, 1u);
-                w = __builtin_amdgcn_readfirstlane(w);
-                if (w >= n_windows) {
-                    if (++xcd_tried == 8u) {
-                        windows = 2u;
-                        break;
-                    }
-                    xcd = (xcd + 1u) & 7u;
-                    continue;
-                }
-                const bool large = w < n_a;
-                const uint32_t wl = large ? w : w - n_a, per = large ? per_a : per_b;
-                const uint32_t seg = wl / per, k = xcd * per + (wl - seg * per);
-                if (k >= (large ? wps_a : wps_b)) continue;  // the last XCDs' eighths may be short
-#else
                 // the first window of a wave is its own number, the later ones come from the launch's cursor (which
                 // counts from zero: + n_waves); a wave whose own number is past the last window never touches the
                 // cursor - on a small launch that is most of them, and 8192 waves x one device-scope atomic on one
@@ -523,14 +598,29 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                     break;
                 }
                 const bool large = w < n_a;
-                const uint32_t wl = large ? w : w - n_a, per = large ? wps_a : wps_b;
-                const uint32_t seg = wl / per, k = wl - seg * per;
-#endif
-                const uint32_t cnt = segmented ? a.seg_counts[seg] * a.count_scale : a.fixed_count;
-                const uint32_t head = cnt > tail ? cnt - tail : 0u;  // rays of this segment handed out in large windows
+                const uint32_t wl = large ? w : w - n_a;
+                uint32_t seg = 0, k = wl;
+                if (segmented) {
+                    // the segment of window wl: the largest s with pref[s] <= wl (pref[0] = 0, pref[n_seg] = all windows
+                    // > wl; empty segments repeat their successor's value), by a 64-ary search with the whole wave
+                    const uint32_t* pref = a.plan + PLAN_HEADER + (large ? 0u : n_pref);
+                    uint32_t span = n_pref, at = 0, at_val = 0;
+                    while (span > 1u) {
+                        const uint32_t step = (span + 63u) / 64u;
+                        const bool in = lane * step < span;
+                        const uint32_t v = in ? pref[at + lane * step] : 0u;
+                        const uint32_t c = (uint32_t)__popcll(__ballot(in && v <= wl)) - 1u;  // lane 0 always qualifies
+                        at_val = __builtin_amdgcn_readlane(v, c);
+                        at += c * step;
+                        span = span - c * step < step ? span - c * step : step;
+                    }
+                    seg = __builtin_amdgcn_readfirstlane(at);
+                    k = wl - at_val;
+                }
+                const uint32_t cnt = segmented ? a.seg_counts[a.seg_div > 1u ? seg / a.seg_div : seg] * a.count_scale : a.fixed_count;
+                const uint32_t head = cnt - win_tail(cnt, tail_num);  // rays of this segment handed out in large windows
                 const uint32_t first = large ? k * chunk : head + k * 64u;
                 const uint32_t end = large ? head : cnt;
-                if (first >= end) continue;  // this segment is shorter than the fullest one
                 const uint32_t len = large ? chunk : 64u;
                 lo = seg * seg_stride + first;
                 hi = seg * seg_stride + (first + len < end ? first + len : end);
@@ -749,10 +839,7 @@ __global__ __launch_bounds__(BLOCK) void k_start(RenderState st) {
         const uint32_t n = regenerate(st, st.rays[0], st.transq[0], seg, 0u, 0u);
         if (threadIdx.x == 0) {
             st.seg_ext[0][seg] = n;
-            if (n) {
-                atomicAdd(st.qcounts, n);
-                atomicMax(st.qmax, n);
-            }
+            if (n) atomicAdd(st.qcounts, n);
         }
     }
 }
@@ -1039,7 +1126,7 @@ __global__ __launch_bounds__(BLOCK, PTX_SHADE_WAVES) void k_shade(DevScene sc, R
             else st_stream(st.sh_T + slot_s, make_float4(T_old.x, T_old.y, T_old.z, u2f(pid)));
             if (st.sh_bounce) st.sh_bounce[slot_s] = (uint8_t)bounce;
             for (uint32_t l = 0; l < (NL ? (uint32_t)NL : n_lights); ++l) {
-                const size_t j = (size_t)slot_s * n_lights + l;
+                const size_t j = ((size_t)seg * n_lights + l) * st.seg_cap + (slot_s - seg_base);  // light-major (RenderState)
                 st_stream(reinterpret_cast<float4*>(st.sh_rays) + 2 * j, make_float4(point_above.x, point_above.y, point_above.z, 0.0f));
                 st_stream(reinterpret_cast<float4*>(st.sh_rays) + 2 * j + 1, make_float4(sh_dir[l].x, sh_dir[l].y, sh_dir[l].z, 1.0f));
                 if (NL != 1) st_stream(st.sh_contrib + j, make_float4(sh_c[l].x, sh_c[l].y, sh_c[l].z, 0.0f));
@@ -1050,12 +1137,9 @@ __global__ __launch_bounds__(BLOCK, PTX_SHADE_WAVES) void k_shade(DevScene sc, R
     if (threadIdx.x == 0) {
         st.seg_ext[q ^ 1u][seg] = n_next;
         st.seg_sh[seg] = n_shadow;
-        if (n_next | n_shadow) {
+        if (n_next | n_shadow)
             atomicAdd(reinterpret_cast<unsigned long long*>(st.qcounts + 2u * round),
                       (unsigned long long)n_next | ((unsigned long long)n_shadow << 32));
-            atomicMax(st.qmax + 2u * round, n_next);
-            atomicMax(st.qmax + 2u * round + 1u, n_shadow);
-        }
     }
     }
 }
@@ -1070,7 +1154,7 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(RenderState st, uint32_t boun
         const uint32_t i = seg * st.seg_cap + k;
         const float4 T = ld_stream(st.sh_T + i);
         const uint32_t pid = f2u(T.w);
-        if (n_lights == 1u) {  // k_shade<1> stored transport * contribution
+        if (n_lights == 1u) {  // k_shade<1> stored transport * contribution (sh_index == i with one light)
             if (!st.sh_occ[i]) {
                 Rad R = st.radiance[pid];
                 R.x = R.x + T.x;
@@ -1082,7 +1166,7 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(RenderState st, uint32_t boun
         }
         V3 incoming = v3(0.0f, 0.0f, 0.0f);
         for (uint32_t l = 0; l < n_lights; ++l) {
-            const size_t j = (size_t)i * n_lights + l;
+            const size_t j = ((size_t)seg * n_lights + l) * st.seg_cap + k;
             V3 c = v3(0.0f, 0.0f, 0.0f);
             if (!st.sh_occ[j]) {
                 const float4 cc = st.sh_contrib[j];
@@ -1114,7 +1198,7 @@ struct CheckArgs {
     uint32_t n_tris;
     const ptx_ray* rays;
     const uint32_t* seg_counts;
-    uint32_t n_seg, seg_cap, scale;
+    uint32_t n_seg, seg_cap, scale, div;  // segment s holds seg_counts[s / div] * scale rays
     uint32_t internal;      // extend queue: t in [0, f32::MAX]
     const ptx_hit* hits;    // nearest-hit answers, or
     const uint8_t* occ;     // occlusion answers
@@ -1127,7 +1211,7 @@ constexpr int CHECK_TILE = 256;
 __global__ __launch_bounds__(BLOCK) void k_check(CheckArgs c) {
     __shared__ TriRec s_tris[CHECK_TILE];
     for (uint32_t seg = blockIdx.x; seg < c.n_seg; seg += gridDim.x) {
-        const uint32_t count = c.seg_counts[seg] * c.scale;
+        const uint32_t count = c.seg_counts[seg / c.div] * c.scale;
         const size_t base = (size_t)seg * c.seg_cap * c.scale;
         for (uint32_t start = 0; start < count; start += BLOCK) {
             const bool active = start + threadIdx.x < count;
@@ -1216,7 +1300,7 @@ __global__ __launch_bounds__(BLOCK) void k_log(RenderState st, LogArgs lg, uint3
                 uint32_t pid, bounce, intersect;
                 float4 ra, rb;
                 if (SHADOW) {
-                    const size_t j = (size_t)slot * n_lights + light;
+                    const size_t j = ((size_t)seg * n_lights + light) * st.seg_cap + k / per;
                     ra = reinterpret_cast<const float4*>(st.sh_rays)[2 * j];
                     rb = reinterpret_cast<const float4*>(st.sh_rays)[2 * j + 1];
                     pid = f2u(st.sh_T[slot].w);
@@ -1392,6 +1476,7 @@ struct ptx_scene {
         DevBuf<uint32_t> perm;  // PTX_FLAG_MATERIAL_QUEUES
         DevBuf<uint2> spill;
         DevBuf<uint32_t> counts, segs;
+        DevBuf<uint32_t> plans;  // [2][plan_words]: window plans of the next extend and the next shadow launch (k_plan)
         ~Pipe() {
             if (ev_accum) (void)hipEventDestroy(ev_accum);
             if (ev_join) (void)hipEventDestroy(ev_join);
@@ -1528,6 +1613,12 @@ void resolve_stamps(ptx_scene* sc) {
     sc->stamps.clear();
 }
 
+// Words of one window plan: the most segments a traversal launch of this scene can have is one per k_shade
+// workgroup and light.
+size_t plan_words(const ptx_scene* sc) {
+    return PLAN_HEADER + 2 * ((size_t)sc->shade_grid * (sc->dev.n_lights ? sc->dev.n_lights : 1u) + 1);
+}
+
 int grow_render_state(ptx_scene* sc, size_t slots, size_t paths, uint32_t rounds) {
     const uint32_t L = sc->dev.n_lights ? sc->dev.n_lights : 1u;
     if (!sc->ev_fork) HIP_TRY(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
@@ -1560,8 +1651,9 @@ int grow_render_state(ptx_scene* sc, size_t slots, size_t paths, uint32_t rounds
         HIP_TRY(p.sh_occ.ensure(slots * L));
         HIP_TRY(p.sh_bounce.ensure(slots));
         if (sc->flags & PTX_FLAG_MATERIAL_QUEUES) HIP_TRY(p.perm.ensure(slots));
-        HIP_TRY(p.counts.ensure((4 + 2 * CURSOR_WORDS) * (size_t)rounds + 4));
+        HIP_TRY(p.counts.ensure((2 + 2 * CURSOR_WORDS) * (size_t)rounds + 2));
         HIP_TRY(p.segs.ensure(4 * (size_t)sc->shade_grid));
+        HIP_TRY(p.plans.ensure(2 * plan_words(sc)));
     }
     if (!sc->totals.p) {
         HIP_TRY(sc->totals.ensure(32));
@@ -1603,8 +1695,9 @@ int check_scene(ptx_scene* sc, const char* who) {
 
 struct SegRange {  // a segmented queue as the traversal kernel sees it (see RenderState)
     const uint32_t* counts = nullptr;
-    const uint32_t* max_ptr = nullptr;
+    const uint32_t* plan = nullptr;  // window plan of the launch (k_plan)
     uint32_t n_seg = 1, cap = 0, scale = 1;
+    uint32_t div = 1;  // segment s takes its count from counts[s / div]
     bool internal = false;
 };
 
@@ -1619,10 +1712,11 @@ int launch_traverse(ptx_scene* sc, const ptx_ray* d_rays, const SegRange& sr, ui
     a.tris = sc->leaf_tris.p;
     a.rays = d_rays;
     a.seg_counts = sr.counts;
-    a.max_ptr = sr.max_ptr;
+    a.plan = sr.plan;
     a.n_seg = sr.n_seg;
     a.seg_cap = sr.cap;
     a.count_scale = sr.scale;
+    a.seg_div = sr.div;
     a.internal = sr.internal ? 1u : 0u;
     a.clip = sc->clip_box ? 1u : 0u;
     for (int k = 0; k < 3; ++k) a.box_lo[k] = sc->box_lo[k], a.box_hi[k] = sc->box_hi[k];
@@ -1656,6 +1750,7 @@ void launch_check(ptx_scene* sc, const ptx_ray* rays, const SegRange& sr, const 
     c.n_seg = sr.n_seg;
     c.seg_cap = sr.cap;
     c.scale = sr.scale;
+    c.div = sr.div ? sr.div : 1u;
     c.internal = sr.internal ? 1u : 0u;
     c.hits = hits;
     c.occ = occ;
@@ -1673,7 +1768,7 @@ uint64_t held_queue_bytes(const ptx_scene* sc) {
         const ptx_scene::Pipe& p = *up;
         b += (p.rays[0].n + p.rays[1].n + p.sh_rays.n) * sizeof(ptx_ray) + p.hits.n * sizeof(ptx_hit);
         b += (p.transq[0].n + p.transq[1].n + p.sh_T.n + p.sh_contrib.n) * sizeof(float4) + p.radiance.n * sizeof(Rad);
-        b += p.perm.n * sizeof(uint32_t) + p.sh_occ.n + p.sh_bounce.n + (p.spill.n + p.spill2.n) * sizeof(uint2) + (p.counts.n + p.segs.n) * sizeof(uint32_t);
+        b += p.perm.n * sizeof(uint32_t) + p.sh_occ.n + p.sh_bounce.n + (p.spill.n + p.spill2.n) * sizeof(uint2) + (p.counts.n + p.segs.n + p.plans.n) * sizeof(uint32_t);
     }
     return b;
 }
@@ -2132,8 +2227,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         st.sh_bounce = sc->raylog_cap ? p.sh_bounce.p : nullptr;
         st.perm = (sc->flags & PTX_FLAG_MATERIAL_QUEUES) ? p.perm.p : nullptr;
         st.qcounts = p.counts.p;
-        st.qmax = p.counts.p + (2 * rounds + 2);
-        st.cursors = p.counts.p + (4 * rounds + 4);
+        st.cursors = p.counts.p + (2 * rounds + 2);
         st.seg_ext[0] = p.segs.p;
         st.seg_ext[1] = p.segs.p + n_seg;
         st.seg_sh = p.segs.p + 2 * (size_t)n_seg;
@@ -2150,12 +2244,17 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         st.n_samples = ns;
         st.n_paths = ns * n_pixels;
         st.first_sample = first_sample + done;
-        HIP_TRY(hipMemsetAsync(p.counts.p, 0, ((4 + 2 * CURSOR_WORDS) * (size_t)rounds + 4) * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(p.counts.p, 0, ((2 + 2 * CURSOR_WORDS) * (size_t)rounds + 2) * sizeof(uint32_t), stream));
+        // window plans (k_plan): [0] of the next extend launch, [1] of the next shadow launch
+        uint32_t* const plan_ext = p.plans.p;
+        uint32_t* const plan_sh = p.plans.p + plan_words(sc);
+        const uint32_t n_waves = (uint32_t)sc->tgrid * (TBLOCK / 64);
         if (rounds == 0) {  // max_bounces == 0: nothing is traced (the reference's loop body never runs)
             HIP_TRY(hipMemsetAsync(p.radiance.p, 0, (size_t)st.n_paths * sizeof(Rad), stream));
         } else {
             Timed tm(sc, stream, KC_GENERATE);
             k_start<<<(int)n_seg, BLOCK, 0, stream>>>(st);
+            k_plan<<<1, 1024, 0, stream>>>(PlanArgs{st.seg_ext[0], n_seg, 1u, 1u, n_waves, plan_ext}, PlanArgs{});
         }
         const bool overlap = sc->overlap_shadow && L > 0;
         hipStream_t sstream = overlap ? p.stream2 : stream;  // stream of the shadow launches
@@ -2166,7 +2265,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
                 ++sc->extend_launches;
                 SegRange sr;
                 sr.counts = st.seg_ext[(b - 1) & 1];
-                sr.max_ptr = st.qmax + 2 * (b - 1);
+                sr.plan = plan_ext;
                 sr.n_seg = n_seg;
                 sr.cap = seg_cap;
                 sr.internal = true;
@@ -2186,6 +2285,9 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
                 else if (L == 2) k_shade<2><<<sg, BLOCK, 0, stream>>>(sc->dev, st, b);
                 else if (L == 4) k_shade<4><<<sg, BLOCK, 0, stream>>>(sc->dev, st, b);
                 else k_shade<0><<<sg, BLOCK, 0, stream>>>(sc->dev, st, b);
+                // both queues k_shade has just written: the shadow launch of this round, the extend launch of the next
+                k_plan<<<2, 1024, 0, stream>>>(PlanArgs{st.seg_ext[b & 1], n_seg, 1u, 1u, n_waves, b < rounds ? plan_ext : nullptr},
+                                               PlanArgs{st.seg_sh, n_seg * L, L ? L : 1u, 1u, n_waves, L ? plan_sh : nullptr});
             }
             if (L > 0) {
                 if (overlap) {
@@ -2197,10 +2299,10 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
                     ++sc->shadow_launches;
                     SegRange sr;
                     sr.counts = st.seg_sh;
-                    sr.max_ptr = st.qmax + 2 * b + 1;
-                    sr.n_seg = n_seg;
+                    sr.plan = plan_sh;
+                    sr.n_seg = n_seg * L;  // light-major: every (segment, light) pair is a segment of the launch
                     sr.cap = seg_cap;
-                    sr.scale = L;
+                    sr.div = L;
                     rc = launch_traverse<true>(sc, st.sh_rays, sr, 0, nullptr, st.sh_occ, st.cursors + 2 * CURSOR_WORDS * (b - 1) + CURSOR_WORDS, sspill,
                                                sc->totals.p + 4, sstream);
                     if (rc) return rc;
