@@ -366,12 +366,14 @@ __device__ inline uint32_t win_tail(uint32_t cnt, uint32_t tail_num) {
     return t < cnt ? t : cnt;
 }
 
-constexpr uint32_t PLAN_HEADER = 8;  // words: chunk, large windows, 64-ray windows, tail_num, then the two prefix arrays
+// plan: chunk, large windows, 64-ray windows, tail_num, 4 spare words; prefix of the large windows [n_seg + 1]; prefix
+// of the 64-ray windows [n_seg + 1]; rays per segment [n_seg]
+constexpr uint32_t PLAN_HEADER = 8;
 struct PlanArgs {
     const uint32_t* counts;  // segment s holds counts[s / div] * scale rays
     uint32_t n_seg, div, scale;
     uint32_t n_waves;        // waves of the traversal launch the plan is for
-    uint32_t* plan;          // [PLAN_HEADER + 2 * (n_seg + 1)], null = nothing to plan
+    uint32_t* plan;          // [PLAN_HEADER + 3 * n_seg + 2], null = nothing to plan
 };
 
 // One workgroup per plan (a launch plans the shadow queue of round b and the extend queue of round b + 1 together:
@@ -426,6 +428,7 @@ __global__ __launch_bounds__(1024) void k_plan(PlanArgs p0, PlanArgs p1) {
         if (s < p.n_seg) {
             pref_a[s] = carry_a + before_a + ia - wa;
             pref_b[s] = carry_b + before_b + ib - wb;
+            pref_b[p.n_seg + 1u + s] = p.counts[s / p.div] * p.scale;  // the segment's rays, for the traversal kernel
         }
         carry_a += tile_a, carry_b += tile_b;
         __syncthreads();
@@ -443,13 +446,11 @@ struct TravArgs {
     uint32_t top_n;            // nodes [0, top_n) are copied into LDS by every workgroup (<= TOP_NODES)
     const TriRec* tris;        // leaf_tris: records in leaf order, f[10] = triangle index | last << 31
     const ptx_ray* rays;
-    // rays [0, fixed_count), or (seg_counts != NULL) the first seg_counts[s] * count_scale rays of every
-    // segment s, segments seg_cap * count_scale rays apart
-    const uint32_t* seg_counts;
+    // rays [0, fixed_count), or (plan != NULL) a SEGMENTED queue: the first rays of each of n_seg segments, seg_cap
+    // rays apart; how many each segment holds, and the windows over them, are in the plan (k_plan)
+    const uint32_t* plan;
     uint32_t n_seg, seg_cap;
-    uint32_t count_scale, fixed_count;
-    uint32_t seg_div;   // segment s of the launch takes its count from seg_counts[s / seg_div] (light-major shadow queues: n_lights)
-    const uint32_t* plan;  // window plan of a segmented launch (k_plan), else null
+    uint32_t fixed_count;
     uint32_t internal;  // rays of the renderer's own extend queue: t in [0, f32::MAX], w fields carry path id / bounce
     uint32_t clip;      // narrow every ray's t range to the bounding box of the triangles (see the refill)
     float box_lo[3], box_hi[3];  // that box, widened
@@ -496,6 +497,12 @@ struct TravArgs {
                 t2 = done ? t2 : u2f(tb); \
                 so = done ? so : st; \
             }
+// Scalar registers count: two 1024-thread workgroups share a CU only while a wave's SGPR allocation stays at 80 or
+// below (measured in round 3: at 82 - the compiler still reports "occupancy 8" - half of the waves of a launch are
+// resident on average, SQ_WAVE_CYCLES x 4 / kernel cycles = 3840 instead of 7450, and every launch takes 1.45x as
+// long; capping the allocation with amdgpu_num_sgpr spills scalars into a 65th VGPR, which costs the same workgroup).
+// That is why the launch's uniform state is kept small: a segmented launch reads everything about its segments from
+// the plan (one pointer), and the Makefile checks the kernel's register counts after every build.
 template <bool ANY, bool COUNT>
 __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
     // The traversal stack of a lane is a ring of LDS_DEPTH entries in LDS that always holds the NEWEST levels: when
@@ -515,8 +522,7 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t gtid = blockIdx.x * TBLOCK + tid;
     const uint32_t so0 = RING - LVL + tid * 8u;  // off(0): level 1 lands in ring slot 0 of this lane's column
-    const bool segmented = a.seg_counts != nullptr;
-    const uint32_t seg_stride = a.seg_cap * a.count_scale;
+    const bool segmented = a.plan != nullptr;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int32_t top_n = (int32_t)a.top_n;
     const uint32_t top_base = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint4*)s_top);
@@ -617,13 +623,13 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                     seg = __builtin_amdgcn_readfirstlane(at);
                     k = wl - at_val;
                 }
-                const uint32_t cnt = segmented ? a.seg_counts[a.seg_div > 1u ? seg / a.seg_div : seg] * a.count_scale : a.fixed_count;
+                const uint32_t cnt = segmented ? a.plan[PLAN_HEADER + 2u * n_pref + seg] : a.fixed_count;
                 const uint32_t head = cnt - win_tail(cnt, tail_num);  // rays of this segment handed out in large windows
                 const uint32_t first = large ? k * chunk : head + k * 64u;
                 const uint32_t end = large ? head : cnt;
                 const uint32_t len = large ? chunk : 64u;
-                lo = seg * seg_stride + first;
-                hi = seg * seg_stride + (first + len < end ? first + len : end);
+                lo = seg * a.seg_cap + first;
+                hi = seg * a.seg_cap + (first + len < end ? first + len : end);
             }
             const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
             const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -1616,7 +1622,7 @@ void resolve_stamps(ptx_scene* sc) {
 // Words of one window plan: the most segments a traversal launch of this scene can have is one per k_shade
 // workgroup and light.
 size_t plan_words(const ptx_scene* sc) {
-    return PLAN_HEADER + 2 * ((size_t)sc->shade_grid * (sc->dev.n_lights ? sc->dev.n_lights : 1u) + 1);
+    return PLAN_HEADER + 3 * ((size_t)sc->shade_grid * (sc->dev.n_lights ? sc->dev.n_lights : 1u) + 1);
 }
 
 int grow_render_state(ptx_scene* sc, size_t slots, size_t paths, uint32_t rounds) {
@@ -1711,12 +1717,9 @@ int launch_traverse(ptx_scene* sc, const ptx_ray* d_rays, const SegRange& sr, ui
     a.root = sc->root_desc;
     a.tris = sc->leaf_tris.p;
     a.rays = d_rays;
-    a.seg_counts = sr.counts;
     a.plan = sr.plan;
     a.n_seg = sr.n_seg;
     a.seg_cap = sr.cap;
-    a.count_scale = sr.scale;
-    a.seg_div = sr.div;
     a.internal = sr.internal ? 1u : 0u;
     a.clip = sc->clip_box ? 1u : 0u;
     for (int k = 0; k < 3; ++k) a.box_lo[k] = sc->box_lo[k], a.box_hi[k] = sc->box_hi[k];
@@ -1730,7 +1733,7 @@ int launch_traverse(ptx_scene* sc, const ptx_ray* d_rays, const SegRange& sr, ui
     a.spill_stride = (uint32_t)grid * TBLOCK;
     a.work = work;
     a.prof = sc->totals.p + (ANY ? 20 : 8);
-    if (!sr.counts) {
+    if (!sr.plan) {
         int need = (int)((n + 63) / 64 + (TBLOCK / 64) - 1) / (TBLOCK / 64);
         if (need < grid) grid = need > 0 ? need : 1;
     }
@@ -2306,6 +2309,17 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
                     rc = launch_traverse<true>(sc, st.sh_rays, sr, 0, nullptr, st.sh_occ, st.cursors + 2 * CURSOR_WORDS * (b - 1) + CURSOR_WORDS, sspill,
                                                sc->totals.p + 4, sstream);
                     if (rc) return rc;
+                    static const bool debug_plan = getenv("PTX_DEBUG_PLAN") != nullptr;  // prints the window plans of every round (stalls the stream)
+                    if (debug_plan) {
+                        (void)hipStreamSynchronize(sstream);
+                        uint32_t h[2][8];
+                        (void)hipMemcpy(h[0], plan_ext, 32, hipMemcpyDeviceToHost);
+                        (void)hipMemcpy(h[1], plan_sh, 32, hipMemcpyDeviceToHost);
+                        uint32_t cur[16];
+                        (void)hipMemcpy(cur, st.cursors + 2 * CURSOR_WORDS * (b - 1), 64, hipMemcpyDeviceToHost);
+                        fprintf(stderr, "[plan] round %u: next-extend chunk %u large %u small %u tail_num %u | shadow chunk %u large %u small %u tail_num %u | cursors ext %u sh %u (n_waves %u)\n",
+                                b, h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3], cur[0], cur[8], n_waves);
+                    }
                     if (sc->flags & PTX_FLAG_CHECK_BRUTE) launch_check(sc, st.sh_rays, sr, nullptr, st.sh_occ, sstream);
                     if (sc->raylog_cap) k_log<true><<<(int)n_seg, BLOCK, 0, sstream>>>(st, LogArgs{sc->raylog.p, sc->raylog_count.p, sc->raylog_cap}, 0u, L);
                 }
