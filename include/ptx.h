@@ -260,7 +260,7 @@ int ptx_intersect_batch_device(ptx_scene* scene, const ptx_ray* d_rays, size_t n
  * harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same kernel and same results; the work
  * cursor and the stack-spill area live in a file-scope device array of the library (34.0 MiB per GPU, held
  * until the process ends) instead of scene-owned allocations, and the call creates no event and takes no
- * timing stamp: it enqueues one 4-byte memset and one kernel on `stream`.  At most PTX_NOALLOC_MAX_RAYS rays
+ * timing stamp: it enqueues one 32-byte memset (the launch's cursor words) and one kernel on `stream`.  At most PTX_NOALLOC_MAX_RAYS rays
  * per call (PTX_E_LIMIT beyond).  All handles on one GPU share that array: calls that overlap on one GPU
  * (two streams, two handles, two threads) race - the caller orders them. */
 #define PTX_NOALLOC_MAX_RAYS (1u << 24)
@@ -292,11 +292,17 @@ int ptx_render_device(ptx_scene* scene, const ptx_pinhole* camera, uint64_t seed
  * buffers are summed onto scenes[0]'s GPU and the result replaces accum_host (which goes in as the starting
  * value of shard 0, so the image-buffer "add into" semantics hold and one scene gives the bits of ptx_render).
  * reduce: PTX_REDUCE_AUTO = RCCL (`ncclReduce`, sum, root 0; librccl is loaded at first use) when the scenes
- * sit on distinct GPUs, else PTX_REDUCE_PEER; PTX_REDUCE_RCCL forces RCCL (also with one scene: a one-rank
- * communicator); PTX_REDUCE_PEER = peer copies to GPU 0 + an add kernel per shard, in shard order (the
+ * sit on distinct GPUs - falling back to PTX_REDUCE_PEER when librccl cannot be loaded or its communicators do
+ * not come up - else PTX_REDUCE_PEER; PTX_REDUCE_RCCL forces RCCL (also with one scene: a one-rank
+ * communicator) and fails hard without it; PTX_REDUCE_PEER = peer copies to GPU 0 + an add kernel per shard, in shard order (the
  * reference's left fold; also the only way when several scenes share a GPU).  progress is called from the
  * render threads, one call at a time, with the samples completed over all shards.
- * ptx_multi_last_reduce_ms: duration of the most recent reduce of this thread's ptx_render_multi call. */
+ * ptx_multi_last_reduce_ms: duration of the most recent reduce of this thread's ptx_render_multi call.
+ * ptx_multi_shutdown: destroys the RCCL communicators the library cached (one set per device list, kept across calls
+ * because ncclCommInitAll costs ~0.5 s); call it when no ptx_render_multi is running, e.g. before unloading the library.
+ * The distinct-GPU paths (ncclCommInitAll over several devices, the grouped ncclReduce, hipMemcpyPeerAsync between
+ * devices) have only run on one-GPU hosts so far - one-rank communicator, handles sharing a GPU: parity unpinned for
+ * N > 1 distinct GPUs until an N-GPU run of tests/test_gpu_multi.py. */
 #define PTX_REDUCE_AUTO 0u
 #define PTX_REDUCE_RCCL 1u
 #define PTX_REDUCE_PEER 2u
@@ -304,6 +310,7 @@ int ptx_render_multi(ptx_scene* const* scenes, uint32_t n_scenes, const ptx_pinh
                      uint32_t first_sample, uint32_t sample_count, float* accum_host, uint32_t reduce,
                      ptx_progress_cb progress, void* user);
 int ptx_multi_last_reduce_ms(double* ms);
+int ptx_multi_shutdown(void);
 /* The sample range of shard `shard` of `n_shards`: GPU g renders [first + g*S/N, first + (g+1)*S/N) — the
  * contiguous form of the reference's "every thread renders iterations_per_thread full frames"
  * (worker.rs:92-104).  Host arithmetic only. */

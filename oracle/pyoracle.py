@@ -378,11 +378,14 @@ class Scene:
         lib().orc_render_raylog(self.h, w, h, C.c_uint64(seed), first_sample, count, _p(raw), C.c_size_t(n))
         return raw
 
-    def bounce_rays(self, w, h, bounces=10, seed=0, threads=8):
+    def bounce_rays(self, w, h, bounces=10, seed=0, threads=8, check=True):
+        """kdtree-tester-cli's ray set; check=False skips the brute-force side (same rays whenever the checked run
+        finds no fail: see orc_bounce_rays2)."""
         fails = C.c_uint64()
         cap = w * h * bounces * (1 + max(self.counts["lights"], 1))
         rays = np.zeros(cap, RAY_DTYPE)
-        n = lib().orc_bounce_rays(self.h, w, h, bounces, C.c_uint64(seed), _p(rays), C.c_size_t(cap), C.byref(fails), threads)
+        lib().orc_bounce_rays2.restype = C.c_size_t
+        n = lib().orc_bounce_rays2(self.h, w, h, bounces, C.c_uint64(seed), _p(rays), C.c_size_t(cap), C.byref(fails), threads, int(bool(check)))
         return rays[:n].copy(), int(fails.value)
 
 

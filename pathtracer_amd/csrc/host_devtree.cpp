@@ -20,7 +20,11 @@ std::string build_device_tree(const ptx_kdnode* in, uint32_t n_nodes, const uint
     // either way.  The reference's trees repeat themselves a lot (cornell_teapot: 239 012 references in 139 958
     // non-empty leaves, 48 890 distinct lists), so the records the traversal gathers from shrink by more than half
     // and more of them stay in the L2.  Which triangles a leaf tests, and in which order, is unchanged.
-    std::unordered_map<std::string, uint32_t> run_of;  // bytes of a list (or of the tail of a stored run) -> offset
+    // Only tails of at most TAIL_MAX triangles are offered for sharing (a key is the bytes of the list it names: every
+    // tail of a 20 000-triangle leaf - a depth-capped or heavily overlapping scene - would cost 2 x 800 MB of keys);
+    // longer lists are still stored once each.  The shipped scenes' longest leaf holds 56 triangles.
+    constexpr uint32_t TAIL_MAX = 64;
+    std::unordered_map<std::string, uint32_t> run_of;  // bytes of a list (or of a short tail of a stored run) -> offset
     {
         auto key_of = [&](const uint32_t* p, uint32_t n) { return std::string(reinterpret_cast<const char*>(p), (size_t)n * 4u); };
         // which lists need a run of their own: taken longest first, a list that is already the tail of a longer one
@@ -36,7 +40,7 @@ std::string build_device_tree(const ptx_kdnode* in, uint32_t n_nodes, const uint
             const uint32_t cnt = in[src].w1 >> 2, off = in[src].w0;
             if (seen.count(key_of(leaf_idx + off, cnt))) continue;
             seen[key_of(leaf_idx + off, cnt)] = true;
-            for (uint32_t k = 1; k < cnt; ++k) seen.emplace(key_of(leaf_idx + off + k, cnt - k), false);
+            for (uint32_t k = cnt > TAIL_MAX ? cnt - TAIL_MAX : 1u; k < cnt; ++k) seen.emplace(key_of(leaf_idx + off + k, cnt - k), false);
         }
         for (uint32_t src : leaves) {
             const uint32_t cnt = in[src].w1 >> 2, off = in[src].w0;
@@ -52,7 +56,8 @@ std::string build_device_tree(const ptx_kdnode* in, uint32_t n_nodes, const uint
                 list.push_back(leaf_idx[off + k] & DESC_PAYLOAD);
             }
             list.back() |= 0x80000000u;
-            for (uint32_t k = 0; k < cnt; ++k) run_of.emplace(key_of(leaf_idx + off + k, cnt - k), (uint32_t)(at + k));
+            run_of.emplace(key_of(leaf_idx + off, cnt), (uint32_t)at);
+            for (uint32_t k = cnt > TAIL_MAX ? cnt - TAIL_MAX : 1u; k < cnt; ++k) run_of.emplace(key_of(leaf_idx + off + k, cnt - k), (uint32_t)(at + k));
         }
     }
     auto leaf_desc = [&](uint32_t src) -> uint32_t {
@@ -114,6 +119,7 @@ using namespace ptx;
 extern "C" int ptx_debug_device_tree(const ptx_kdnode* nodes, uint32_t n_nodes, const uint32_t* leaf_indices, uint32_t n_leaf_indices,
                                      uint32_t n_triangles, uint32_t top_nodes, uint32_t* node_words, uint32_t* records, uint32_t counts[4]) {
     if (!nodes || !counts || (n_leaf_indices && !leaf_indices)) return fail(PTX_E_ARG, "ptx_debug_device_tree: null argument");
+    return guarded("ptx_debug_device_tree", [&]() -> int {
     const std::string why = validate_flat_tree(nodes, n_nodes, leaf_indices, n_leaf_indices, n_triangles);
     if (!why.empty()) return fail(PTX_E_ARG, "ptx_debug_device_tree: " + why);
     std::vector<DevNode> dn;
@@ -129,4 +135,5 @@ extern "C" int ptx_debug_device_tree(const ptx_kdnode* nodes, uint32_t n_nodes, 
     if (records)
         for (size_t i = 0; i < dl.size(); ++i) records[i] = dl[i];
     return PTX_OK;
+    });
 }

@@ -1,6 +1,8 @@
 // host_internal.hpp — declarations shared by the translation units of libptx_mi355x.so.
 #pragma once
 #include <cstdint>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -12,6 +14,29 @@ namespace ptx {
 // error plumbing (thread-local text behind ptx_last_error)
 int fail(int code, const std::string& what);
 void clear_error();
+
+// No exception crosses the C ABI (include/ptx.h): the body of an entry point that allocates with C++ containers
+// or starts threads runs inside this; std::bad_alloc becomes PTX_E_OOM, anything else PTX_E_HIP with its text.
+template <class F>
+int guarded(const char* who, F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        try {
+            return fail(PTX_E_OOM, std::string(who) + ": out of host memory");
+        } catch (...) {
+            return PTX_E_OOM;
+        }
+    } catch (const std::exception& e) {
+        try {
+            return fail(PTX_E_HIP, std::string(who) + ": " + e.what());
+        } catch (...) {
+            return PTX_E_HIP;
+        }
+    } catch (...) {
+        return PTX_E_HIP;
+    }
+}
 
 void build_flat_kdtree(const float* tris, uint32_t n, const ptx_sah_cost& sah,
                        std::vector<ptx_kdnode>& nodes, std::vector<uint32_t>& leaves);

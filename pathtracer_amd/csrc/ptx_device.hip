@@ -255,7 +255,10 @@ constexpr uint32_t TRI_BATCH_ANYHIT = PTX_TRI_BATCH_ANY;
 #define PTX_TAIL_ROUNDS 2u  // 64-ray windows per wave handed out after the large ones
 #endif
 #ifndef PTX_MAX_CHUNK
-#define PTX_MAX_CHUNK 512u
+#define PTX_MAX_CHUNK 1024u  // largest window of a nearest-hit launch
+#endif
+#ifndef PTX_MAX_CHUNK_ANY
+#define PTX_MAX_CHUNK_ANY 512u  // ... of an any-hit launch
 #endif
 #ifndef PTX_SHADE_WAVES
 #define PTX_SHADE_WAVES 1  // minimum waves per SIMD the register allocation of k_shade must allow
@@ -349,10 +352,14 @@ static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
 struct WinShape {
     uint32_t chunk, tail_num;  // tail_num / 65536 = share of every segment that goes out in 64-ray windows
 };
-__device__ inline WinShape win_shape(unsigned long long total_rays, uint32_t n_waves) {
+// The largest window differs by kind (round 3, sr2 3840x2160 where nine camera rays in ten miss the scene's box and
+// retire at once: its extend launches are bound by the cursor, 512 rays per ~16 ns = 32 Grays/s, and 1024-ray windows
+// take 19 % off them; the any-hit launches lose 3 % with 1024 and cornell_teapot's extend does not care).
+__device__ inline WinShape win_shape(unsigned long long total_rays, uint32_t n_waves, bool any_hit) {
     const unsigned long long est = total_rays / (n_waves * 4ull);
+    const uint32_t max_chunk = any_hit ? PTX_MAX_CHUNK_ANY : PTX_MAX_CHUNK;
     WinShape ws{64u, 0u};
-    while (ws.chunk < PTX_MAX_CHUNK && 2ull * ws.chunk <= est) ws.chunk *= 2u;
+    while (ws.chunk < max_chunk && 2ull * ws.chunk <= est) ws.chunk *= 2u;
     if (ws.chunk > 64u) {
         const unsigned long long tail_total = (unsigned long long)PTX_TAIL_ROUNDS * n_waves * 64ull;
         const unsigned long long num = tail_total * 65536ull / total_rays;  // (chunk > 64 implies total_rays > 0)
@@ -373,6 +380,7 @@ struct PlanArgs {
     const uint32_t* counts;  // segment s holds counts[s / div] * scale rays
     uint32_t n_seg, div, scale;
     uint32_t n_waves;        // waves of the traversal launch the plan is for
+    uint32_t any_hit;        // ... and its kind
     uint32_t* plan;          // [PLAN_HEADER + 3 * n_seg + 2], null = nothing to plan
 };
 
@@ -394,7 +402,7 @@ __global__ __launch_bounds__(1024) void k_plan(PlanArgs p0, PlanArgs p1) {
     if (tid == 0) {
         unsigned long long total = 0;
         for (int w = 0; w < 16; ++w) total += s_sum[w];
-        s_shape = win_shape(total, p.n_waves);
+        s_shape = win_shape(total, p.n_waves, p.any_hit != 0u);
         p.plan[0] = s_shape.chunk;
         p.plan[3] = s_shape.tail_num;
     }
@@ -535,7 +543,7 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
     if (segmented) {
         chunk = a.plan[0], n_a = a.plan[1], n_windows = n_a + a.plan[2], tail_num = a.plan[3];
     } else {
-        const WinShape ws = win_shape(a.fixed_count, n_waves);
+        const WinShape ws = win_shape(a.fixed_count, n_waves, ANY);
         const uint32_t tail = win_tail(a.fixed_count, ws.tail_num);
         chunk = ws.chunk, tail_num = ws.tail_num;
         n_a = (a.fixed_count - tail + chunk - 1u) / chunk;
@@ -1556,7 +1564,10 @@ hipEvent_t take_event(ptx_scene* sc) {
         return e;
     }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    if (hipEventCreate(&e) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;  // the launch this would have timed simply goes untimed (see Timed)
+    }
     return e;
 }
 
@@ -1571,7 +1582,13 @@ struct Timed {  // RAII bracket of one launch with two events when timing is on
             st.b = take_event(sc);
             st.cls = cls;
             st.round = round;
-            (void)hipEventRecord(st.a, stream);
+            if (!st.a || !st.b) {  // no event to be had: this launch is not timed
+                if (st.a) sc->free_events.push_back(st.a);
+                if (st.b) sc->free_events.push_back(st.b);
+                on = false;
+            } else {
+                (void)hipEventRecord(st.a, stream);
+            }
         }
     }
     ~Timed() {
@@ -1790,7 +1807,14 @@ uint64_t auto_queue_bytes(const ptx_scene* sc) {
 
 extern "C" {
 
+static int scene_create_impl(const ptx_scene_desc* d, uint32_t flags, ptx_scene** out);
+
 int ptx_scene_create(const ptx_scene_desc* d, uint32_t flags, ptx_scene** out) {
+    // (vectors, strings and maps below: std::bad_alloc must not cross the boundary)
+    return guarded("ptx_scene_create", [&]() -> int { return scene_create_impl(d, flags, out); });
+}
+
+static int scene_create_impl(const ptx_scene_desc* d, uint32_t flags, ptx_scene** out) {
     if (!d || !out) return fail(PTX_E_ARG, "ptx_scene_create: null argument");
     if (!d->nodes || d->n_nodes == 0) return fail(PTX_E_ARG, "ptx_scene_create: tree has no nodes");
     if (d->n_triangles && !d->triangles) return fail(PTX_E_ARG, "ptx_scene_create: triangles missing");
@@ -1991,6 +2015,7 @@ void ptx_scene_destroy(ptx_scene* scene) {
 }
 
 int ptx_intersect_batch_device(ptx_scene* sc, const ptx_ray* d_rays, size_t n, ptx_hit* d_hits, void* stream) {
+    return guarded("ptx_intersect_batch_device", [&]() -> int {
     int rc = check_scene(sc, "ptx_intersect_batch_device");
     if (rc) return rc;
     if (n == 0) return PTX_OK;
@@ -2008,6 +2033,7 @@ int ptx_intersect_batch_device(ptx_scene* sc, const ptx_ray* d_rays, size_t n, p
     HIP_TRY(hipEventRecord(sc->ev_batch, (hipStream_t)stream));
     sc->batch_pending = true;
     return rc;
+    });
 }
 
 int ptx_intersect_batch_device_noalloc(ptx_scene* sc, const ptx_ray* d_rays, size_t n, ptx_hit* d_hits, void* stream) {
@@ -2028,6 +2054,7 @@ int ptx_intersect_batch_device_noalloc(ptx_scene* sc, const ptx_ray* d_rays, siz
 }
 
 int ptx_occluded_batch_device(ptx_scene* sc, const ptx_ray* d_rays, size_t n, uint8_t* d_out, void* stream) {
+    return guarded("ptx_occluded_batch_device", [&]() -> int {
     int rc = check_scene(sc, "ptx_occluded_batch_device");
     if (rc) return rc;
     if (n == 0) return PTX_OK;
@@ -2045,9 +2072,11 @@ int ptx_occluded_batch_device(ptx_scene* sc, const ptx_ray* d_rays, size_t n, ui
     HIP_TRY(hipEventRecord(sc->ev_batch, (hipStream_t)stream));
     sc->batch_pending = true;
     return rc;
+    });
 }
 
 int ptx_intersect_batch(ptx_scene* sc, const ptx_ray* rays, size_t n, ptx_hit* hits) {
+    return guarded("ptx_intersect_batch", [&]() -> int {
     int rc = check_scene(sc, "ptx_intersect_batch");
     if (rc) return rc;
     if (n == 0) return PTX_OK;
@@ -2063,6 +2092,7 @@ int ptx_intersect_batch(ptx_scene* sc, const ptx_ray* rays, size_t n, ptx_hit* h
         HIP_TRY(hipMemcpy(hits + at, sc->stage_hits.p, m * sizeof(ptx_hit), hipMemcpyDeviceToHost));
     }
     return PTX_OK;
+    });
 }
 
 int ptx_set_batch_samples(ptx_scene* sc, uint32_t samples_per_batch) {
@@ -2257,7 +2287,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         } else {
             Timed tm(sc, stream, KC_GENERATE);
             k_start<<<(int)n_seg, BLOCK, 0, stream>>>(st);
-            k_plan<<<1, 1024, 0, stream>>>(PlanArgs{st.seg_ext[0], n_seg, 1u, 1u, n_waves, plan_ext}, PlanArgs{});
+            k_plan<<<1, 1024, 0, stream>>>(PlanArgs{st.seg_ext[0], n_seg, 1u, 1u, n_waves, 0u, plan_ext}, PlanArgs{});
         }
         const bool overlap = sc->overlap_shadow && L > 0;
         hipStream_t sstream = overlap ? p.stream2 : stream;  // stream of the shadow launches
@@ -2289,8 +2319,8 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
                 else if (L == 4) k_shade<4><<<sg, BLOCK, 0, stream>>>(sc->dev, st, b);
                 else k_shade<0><<<sg, BLOCK, 0, stream>>>(sc->dev, st, b);
                 // both queues k_shade has just written: the shadow launch of this round, the extend launch of the next
-                k_plan<<<2, 1024, 0, stream>>>(PlanArgs{st.seg_ext[b & 1], n_seg, 1u, 1u, n_waves, b < rounds ? plan_ext : nullptr},
-                                               PlanArgs{st.seg_sh, n_seg * L, L ? L : 1u, 1u, n_waves, L ? plan_sh : nullptr});
+                k_plan<<<2, 1024, 0, stream>>>(PlanArgs{st.seg_ext[b & 1], n_seg, 1u, 1u, n_waves, 0u, b < rounds ? plan_ext : nullptr},
+                                               PlanArgs{st.seg_sh, n_seg * L, L ? L : 1u, 1u, n_waves, 1u, L ? plan_sh : nullptr});
             }
             if (L > 0) {
                 if (overlap) {
@@ -2372,7 +2402,7 @@ int internal_render(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uint32
                     float* d_accum, void* stream, ptx_progress_cb progress, void* user) {
     int rc = check_scene(sc, "ptx_render_multi");
     if (rc) return rc;
-    return render_impl(sc, cam, seed, first_sample, sample_count, d_accum, (hipStream_t)stream, progress, user);
+    return guarded("ptx_render_multi", [&]() -> int { return render_impl(sc, cam, seed, first_sample, sample_count, d_accum, (hipStream_t)stream, progress, user); });
 }
 int internal_device(const ptx_scene* sc) { return sc->device; }
 int internal_multi_slot(ptx_scene* sc, size_t n_floats, float** accum, float** tmp, void** stream) {
@@ -2394,7 +2424,7 @@ int ptx_render_device(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uint
                       uint32_t sample_count, float* d_accum, void* stream) {
     int rc = check_scene(sc, "ptx_render_device");
     if (rc) return rc;
-    return render_impl(sc, cam, seed, first_sample, sample_count, d_accum, (hipStream_t)stream, nullptr, nullptr);
+    return guarded("ptx_render_device", [&]() -> int { return render_impl(sc, cam, seed, first_sample, sample_count, d_accum, (hipStream_t)stream, nullptr, nullptr); });
 }
 
 int ptx_render_region_device(ptx_scene* sc, const ptx_pinhole* cam, uint32_t x, uint32_t y, uint32_t width, uint32_t height,
@@ -2402,7 +2432,7 @@ int ptx_render_region_device(ptx_scene* sc, const ptx_pinhole* cam, uint32_t x, 
     int rc = check_scene(sc, "ptx_render_region_device");
     if (rc) return rc;
     const Region reg{x, y, width, height};
-    return render_impl(sc, cam, seed, first_sample, sample_count, d_accum, (hipStream_t)stream, nullptr, nullptr, &reg);
+    return guarded("ptx_render_region_device", [&]() -> int { return render_impl(sc, cam, seed, first_sample, sample_count, d_accum, (hipStream_t)stream, nullptr, nullptr, &reg); });
 }
 
 int ptx_render(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uint32_t first_sample, uint32_t sample_count,
@@ -2415,7 +2445,7 @@ int ptx_render(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uint32_t fi
     HIP_TRY(sc->stage_accum.ensure(n));
     HIP_TRY(hipMemcpy(sc->stage_accum.p, accum_host, n * sizeof(float), hipMemcpyHostToDevice));
     auto t0 = std::chrono::steady_clock::now();
-    rc = render_impl(sc, cam, seed, first_sample, sample_count, sc->stage_accum.p, nullptr, progress, user);
+    rc = guarded("ptx_render", [&]() -> int { return render_impl(sc, cam, seed, first_sample, sample_count, sc->stage_accum.p, nullptr, progress, user); });
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     sc->total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -2438,6 +2468,7 @@ int ptx_tonemap_rgb8_device(const float* d_accum, uint32_t width, uint32_t heigh
 }
 
 int ptx_last_batch_counts(ptx_scene* sc, uint32_t* ext, uint32_t* sh, uint32_t n) {
+    return guarded("ptx_last_batch_counts", [&]() -> int {
     int rc = check_scene(sc, "ptx_last_batch_counts");
     if (rc) return rc;
     if (!ext || !sh) return fail(PTX_E_ARG, "ptx_last_batch_counts: null argument");
@@ -2451,9 +2482,11 @@ int ptx_last_batch_counts(ptx_scene* sc, uint32_t* ext, uint32_t* sh, uint32_t n
         sh[b] = b < B ? host[2 * b + 3] : 0;
     }
     return PTX_OK;
+    });
 }
 
 int ptx_stats(ptx_scene* sc, ptx_counters* out) {
+    return guarded("ptx_stats", [&]() -> int {
     int rc = check_scene(sc, "ptx_stats");
     if (rc) return rc;
     if (!out) return fail(PTX_E_ARG, "ptx_stats: null argument");
@@ -2478,9 +2511,11 @@ int ptx_stats(ptx_scene* sc, ptx_counters* out) {
     out->shadow_ms = sc->class_ms[KC_SHADOW];
     out->total_ms = sc->total_ms;
     return PTX_OK;
+    });
 }
 
 int ptx_round_times(ptx_scene* sc, double* extend_ms, double* shadow_ms, uint32_t n) {
+    return guarded("ptx_round_times", [&]() -> int {
     int rc = check_scene(sc, "ptx_round_times");
     if (rc) return rc;
     if (!extend_ms || !shadow_ms) return fail(PTX_E_ARG, "ptx_round_times: null argument");
@@ -2491,6 +2526,7 @@ int ptx_round_times(ptx_scene* sc, double* extend_ms, double* shadow_ms, uint32_
         shadow_ms[r] = r < sc->round_ms[1].size() ? sc->round_ms[1][r] : 0.0;
     }
     return PTX_OK;
+    });
 }
 
 int ptx_debug_loop_profile(ptx_scene* sc, uint64_t* out24) {
@@ -2516,6 +2552,7 @@ int ptx_check_report(ptx_scene* sc, uint64_t* n_checked, uint64_t* n_fails) {
 }
 
 int ptx_check_fail_log(ptx_scene* sc, uint8_t* out, uint32_t cap_records, uint32_t* n_written) {
+    return guarded("ptx_check_fail_log", [&]() -> int {
     uint64_t n_fails = 0;
     int rc = ptx_check_report(sc, nullptr, &n_fails);
     if (rc) return rc;
@@ -2543,6 +2580,7 @@ int ptx_check_fail_log(ptx_scene* sc, uint8_t* out, uint32_t cap_records, uint32
     }
     *n_written = n;
     return PTX_OK;
+    });
 }
 
 int ptx_raylog_enable(ptx_scene* sc, uint64_t max_records) {
@@ -2559,6 +2597,7 @@ int ptx_raylog_enable(ptx_scene* sc, uint64_t max_records) {
 }
 
 int ptx_raylog_read(ptx_scene* sc, uint8_t* out, uint64_t cap_records, uint64_t* n_written, uint64_t* n_dropped) {
+    return guarded("ptx_raylog_read", [&]() -> int {
     int rc = check_scene(sc, "ptx_raylog_read");
     if (rc) return rc;
     if (!sc->raylog_cap) return fail(PTX_E_ARG, "ptx_raylog_read: the ray log is off (ptx_raylog_enable)");
@@ -2589,9 +2628,11 @@ int ptx_raylog_read(ptx_scene* sc, uint8_t* out, uint64_t cap_records, uint64_t*
     if (n_dropped) *n_dropped = produced - n;
     HIP_TRY(hipMemset(sc->raylog_count.p, 0, sizeof(unsigned long long)));  // the log starts over
     return PTX_OK;
+    });
 }
 
 int ptx_stats_reset(ptx_scene* sc) {
+    return guarded("ptx_stats_reset", [&]() -> int {
     int rc = check_scene(sc, "ptx_stats_reset");
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
@@ -2606,6 +2647,7 @@ int ptx_stats_reset(ptx_scene* sc) {
     if (sc->check_count.p) HIP_TRY(hipMemset(sc->check_count.p, 0, 2 * sizeof(unsigned long long)));
     sc->extend_launches = sc->shadow_launches = 0;
     return PTX_OK;
+    });
 }
 
 }  // extern "C"

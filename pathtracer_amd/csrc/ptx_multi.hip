@@ -20,6 +20,9 @@
 
 #include <dlfcn.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include <atomic>
 #include <chrono>
 #include <map>
@@ -171,15 +174,21 @@ int reduce_peer(std::vector<Shard>& sh, size_t n_floats) {
     return PTX_OK;
 }
 
-int reduce_rccl(std::vector<Shard>& sh, size_t n_floats) {
+constexpr int PTX_E_NO_RCCL = -1000;  // internal: RCCL could not be set up (nothing was enqueued yet)
+
+int reduce_rccl(std::vector<Shard>& sh, size_t n_floats, bool soft_setup) {
     std::lock_guard<std::mutex> lock(g_mu);
-    if (!load_rccl()) return fail(PTX_E_HIP, "ptx_render_multi: " + g_rccl.why);
+    if (!load_rccl()) return fail(soft_setup ? PTX_E_NO_RCCL : PTX_E_HIP, "ptx_render_multi: " + g_rccl.why);
     std::vector<int> devs;
     for (auto& s : sh) devs.push_back(s.device);
     auto it = g_comms.find(devs);
     if (it == g_comms.end()) {
         std::vector<ncclComm_t> comms(devs.size());
-        RCCL_TRY(g_rccl.CommInitAll(comms.data(), (int)devs.size(), devs.data()));
+        const ncclResult_t r = g_rccl.CommInitAll(comms.data(), (int)devs.size(), devs.data());
+        if (r != ncclSuccess) {
+            const int rc = rccl_fail(r, "ncclCommInitAll");
+            return soft_setup ? PTX_E_NO_RCCL : rc;
+        }
         it = g_comms.emplace(devs, std::move(comms)).first;
     }
     std::vector<ncclComm_t>& comms = it->second;
@@ -222,8 +231,33 @@ int ptx_multi_last_reduce_ms(double* ms) {
     return PTX_OK;
 }
 
+int ptx_multi_shutdown(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    int rc = PTX_OK;
+    int before = 0;
+    (void)hipGetDevice(&before);
+    for (auto& kv : g_comms)
+        for (size_t g = 0; g < kv.second.size(); ++g) {
+            (void)hipSetDevice(kv.first[g]);
+            if (g_rccl.CommDestroy && g_rccl.CommDestroy(kv.second[g]) != ncclSuccess) rc = fail(PTX_E_HIP, "ptx_multi_shutdown: ncclCommDestroy failed");
+        }
+    g_comms.clear();
+    (void)hipSetDevice(before);
+    return rc;
+}
+
+static int render_multi_impl(ptx_scene* const* scenes, uint32_t n_scenes, const ptx_pinhole* cam, uint64_t seed, uint32_t first_sample,
+                             uint32_t sample_count, float* accum_host, uint32_t reduce, ptx_progress_cb progress, void* user);
+
 int ptx_render_multi(ptx_scene* const* scenes, uint32_t n_scenes, const ptx_pinhole* cam, uint64_t seed, uint32_t first_sample,
                      uint32_t sample_count, float* accum_host, uint32_t reduce, ptx_progress_cb progress, void* user) {
+    return guarded("ptx_render_multi", [&]() -> int {
+        return render_multi_impl(scenes, n_scenes, cam, seed, first_sample, sample_count, accum_host, reduce, progress, user);
+    });
+}
+
+static int render_multi_impl(ptx_scene* const* scenes, uint32_t n_scenes, const ptx_pinhole* cam, uint64_t seed, uint32_t first_sample,
+                             uint32_t sample_count, float* accum_host, uint32_t reduce, ptx_progress_cb progress, void* user) {
     if (!scenes || n_scenes == 0) return fail(PTX_E_ARG, "ptx_render_multi: no scenes");
     if (n_scenes > 64) return fail(PTX_E_LIMIT, "ptx_render_multi: more than 64 scenes");
     if (!cam || !accum_host) return fail(PTX_E_ARG, "ptx_render_multi: null argument");
@@ -280,18 +314,36 @@ int ptx_render_multi(ptx_scene* const* scenes, uint32_t n_scenes, const ptx_pinh
         else if (s.rc != PTX_OK) s.error = ptx_last_error();  // thread-local: carried over to the caller's thread below
     };
     {
-        std::vector<std::thread> threads;
-        for (uint32_t g = 1; g < n_scenes; ++g) threads.emplace_back(work, g);
+        // whatever happens while the threads are being started (std::system_error), the ones already running are
+        // joined before this frame is left: a joinable std::thread must never be destroyed
+        struct Joiner {
+            std::vector<std::thread> threads;
+            ~Joiner() {
+                for (auto& t : threads)
+                    if (t.joinable()) t.join();
+            }
+        } joiner;
+        joiner.threads.reserve(n_scenes);
+        for (uint32_t g = 1; g < n_scenes; ++g) joiner.threads.emplace_back(work, g);
         work(0);  // the calling thread renders shard 0
-        for (auto& t : threads) t.join();
     }
     int rc = PTX_OK;
     for (auto& s : sh)
         if (s.rc != PTX_OK && rc == PTX_OK) rc = fail(s.rc, s.error.empty() ? "ptx_render_multi: a shard failed" : s.error);
     if (rc == PTX_OK) {
         const auto r0 = std::chrono::steady_clock::now();
-        if (how == PTX_REDUCE_RCCL) rc = reduce_rccl(sh, n_floats);
-        else if (n_scenes > 1) rc = reduce_peer(sh, n_floats);
+        if (how == PTX_REDUCE_RCCL) {
+            rc = reduce_rccl(sh, n_floats, /*setup_only=*/reduce == PTX_REDUCE_AUTO);
+            if (rc == PTX_E_NO_RCCL) {
+                // PTX_REDUCE_AUTO and librccl cannot be loaded or its communicators do not come up: the peer fold needs
+                // neither (an explicit PTX_REDUCE_RCCL keeps the hard error)
+                if (getenv("PTX_VERBOSE")) fprintf(stderr, "[ptx] RCCL unavailable (%s): summing with peer copies\n", ptx_last_error());
+                rc = internal_multi_slot(sh[0].scene, n_floats, &sh[0].accum, &sh[0].tmp, (void**)&sh[0].stream);
+                if (rc == PTX_OK) rc = reduce_peer(sh, n_floats);
+            }
+        } else if (n_scenes > 1) {
+            rc = reduce_peer(sh, n_floats);
+        }
         t_last_reduce_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count();
     }
     if (rc == PTX_OK) {

@@ -271,7 +271,12 @@ def test_material_keyed_shade_queues_change_no_bit(name, w, h, spp):
     plain, keyed = scene.upload(), scene.upload(flags=pt.FLAG_MATERIAL_QUEUES)
     ph = scene.pinhole(w, h)
     want = plain.render(ph, spp, seed=6)
-    assert keyed.render(ph, spp, seed=6).tobytes() == want.tobytes()
+    got = keyed.render(ph, spp, seed=6)
+    assert got.tobytes() == want.tobytes()
+    # ... and against the oracle itself (Material::sample per path, tracing/src/material.rs:167-191), not only the
+    # unflagged HIP path: spp threads x 1 iteration = the same left fold of one-sample buffers
+    expect, _ = orc.Scene(os.path.join(SCENES, name + ".obj"), max_bounces=8).render(w, h, threads=spp, iterations_per_thread=1, mode=1, seed=6)
+    assert got.tobytes() == expect.tobytes()
     keyed.set_queue_slots(4096)  # far fewer slots than paths: regeneration rounds mix bounces inside a segment
     assert keyed.render(ph, spp, seed=6).tobytes() == want.tobytes()
     keyed.set_queue_slots(0)

@@ -20,18 +20,37 @@ TEAPOT = os.path.join(ROOT, "scenes", "cornell_teapot.obj")
 W = H = 1080
 
 
-def test_extend_two_million_rays_bit_exact():
-    """configs[1] at scale: bounced + synthetic rays, every hit record equal to the pointer-tree traversal."""
+def test_config2_full_size_hit_records_bit_exact():
+    """configs[1] at the size SURVEY 8d states: ray set A = the kdtree-tester-cli bounced set at the reference's
+    defaults, 512 x 512 pixels / 10 bounces (ray_bouncer.rs:57-120; 2.69 M extend + shadow rays), ray set B = 2^24
+    uniform + 2^22 segment + 2^21 axis-parallel (+-0) rays, seed 0x5EED0001: 25.8 M rays, every hit record
+    (index, t, u, v) of the GPU equal to the oracle's POINTER-tree traversal bit for bit.
+
+    Set A is regenerated here without its brute-force side (35 G triangle tests: minutes) and must hash to the set the
+    CHECKED generator produced (tests/golden/config2_fullsize.json, written by tests/golden/make_config2_golden.py,
+    which also recorded 0 disagreements with brute force); the oracle's hit records are pinned by the same file."""
+    import hashlib
+    import json
+
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "config2_fullsize.json")))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
     ref = orc.Scene(TEAPOT)
-    bounced, fails = ref.bounce_rays(360, 360, 10, seed=11, threads=16)
-    assert fails == 0
+    bounced, _ = ref.bounce_rays(512, 512, gold["bounces"], seed=gold["seed_bounced"], threads=16, check=False)
+    assert len(bounced) == gold["bounced_rays"] and sha(bounced) == gold["bounced_rays_sha256"]
     tris = ref.export()["triangles"].reshape(-1, 3, 3)
-    rays = np.concatenate([bounced, synthetic_rays(tris.min((0, 1)), tris.max((0, 1)), 1 << 20, 0x5EED0002)])
-    assert len(rays) > 2_000_000
-    want = ref.tree().intersect(rays, threads=16)
+    synth = synthetic_rays(tris.min((0, 1)), tris.max((0, 1)), gold["synthetic_n"], gold["seed_synthetic"])
+    assert len(synth) == gold["synthetic_rays"] == (1 << 24) + (1 << 22) + (1 << 21)
+    tree = ref.tree()
     dev = pt.LoadedScene(TEAPOT).upload()
-    got = dev.intersect(rays)
-    assert_hits_equal(got, want)
+    for rays, key in ((bounced, "bounced"), (synth, "synthetic")):
+        want = tree.intersect(rays, threads=16)
+        got = dev.intersect(rays)
+        assert_hits_equal(got, want)
+        if sha(rays) == gold[key + "_rays_sha256"]:  # (the synthetic set goes through numpy's sin / cos: same image, same bits)
+            assert sha(got) == gold[key + "_hits_sha256"]
+        else:
+            assert key == "synthetic"
+        assert 0.3 < (want["index"] != 0xFFFFFFFF).mean() < 0.99
     dev.close()
 
 

@@ -406,6 +406,36 @@ def test_device_tree_layout(name):
     assert np.array_equal(r2, records)
 
 
+def test_device_tree_huge_leaves_stay_cheap():
+    """A depth-capped or heavily overlapping scene can hold leaves of tens of thousands of triangles.  Tail sharing is
+    keyed by the bytes of a list, so it is only offered for tails of at most 64 triangles: a 20 000-triangle leaf costs
+    its own length in keys, not its length squared (2 x 800 MB before), and the layout stays correct: the long list is
+    stored once, a short tail of it points into its run, a long tail gets a run of its own."""
+    import resource
+    import time
+
+    n = 20_000
+    tris = np.zeros((n, 9), np.float32)
+    tris[:, 0], tris[:, 4], tris[:, 8] = np.arange(n), 1.0, 1.0  # (never intersected here)
+    nodes = np.zeros(5, pt.NODE_DTYPE)  # root(x) -> [leaf A | node(y) -> [leaf B | leaf C]]
+    leaf = np.concatenate([np.arange(n), np.arange(n - 40, n), np.arange(100, n)]).astype(np.uint32)
+    nodes["w0"][0], nodes["w1"][0] = np.float32(0.5).view(np.uint32), (2 << 2) | 0
+    nodes["w0"][1], nodes["w1"][1] = 0, (n << 2) | 3                     # A: all n triangles
+    nodes["w0"][2], nodes["w1"][2] = np.float32(0.5).view(np.uint32), (4 << 2) | 1
+    nodes["w0"][3], nodes["w1"][3] = n, (40 << 2) | 3                    # B: the last 40 of A (a short tail: shared)
+    nodes["w0"][4], nodes["w1"][4] = n + 40, ((n - 100) << 2) | 3        # C: A without its first 100 (a long tail: own run)
+    kd = pt.KdTree(tris, nodes, leaf)
+    before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    t0 = time.perf_counter()
+    words, records, root, top_n = kd.device_layout()
+    assert time.perf_counter() - t0 < 5.0
+    assert resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - before < 200_000  # KiB; the quadratic version needed GBs
+    assert len(words) == 2 and len(records) == n + (n - 100)
+    assert _walk_device_tree(kd, words, records, root) == 3
+    a_desc, b_desc, c_desc = int(words[0, 2]), int(words[1, 2]), int(words[1, 3])
+    assert a_desc == 0x80000000 and b_desc == 0x80000000 | (n - 40) and c_desc == 0x80000000 | n
+
+
 def test_device_tree_rejects_malformed():
     scene = pt.LoadedScene(os.path.join(SCENES, "cornell.obj"))
     kd = scene.kdtree()

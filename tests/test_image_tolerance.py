@@ -52,12 +52,15 @@ def measure(counter, seq_a, seq_b, n_pixels):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,w,h,spp", [("cornell_textured", 128, 128, 128), ("cornell_teapot", 128, 128, 128), ("sr2", 192, 108, 128)])
+@pytest.mark.parametrize("name,w,h,spp", [("cornell_textured", 128, 128, 128), ("cornell_teapot", 128, 128, 128), ("sr2", 192, 108, 128),
+                                          ("cornell_teapot", 1080, 1080, 64), ("cornell_textured", 1080, 1080, 64)])
 def test_gpu_image_within_tolerance_of_the_sequential_cpu_render(name, w, h, spp):
     """north_star's second correctness leg on the GPU: the HIP render against the reference-structured CPU
-    render (sequential per-thread streams, libm trig) at equal samples per pixel, three scenes (texture +
-    refraction, the headline scene, 4 lights + non-square camera).  The measured numbers are written to
-    gpurun_out/rmse_leg.json when that directory exists (they are quoted in DESIGN.md 6)."""
+    render (sequential per-thread streams, libm trig; T threads x N iterations, tracing/src/worker.rs:27-50) at equal
+    samples per pixel: three scenes small (texture + refraction, the headline scene, 4 lights + non-square camera) and
+    configs[2] / configs[3] at their full 1080 x 1080 (64 spp = 16 threads x 4 iterations; with 1.17 M pixels the bias
+    bar is 1 / 1080 of the reseed RMSE).  The measured numbers are written to gpurun_out/rmse_leg.json when that
+    directory exists (they are quoted in DESIGN.md 6)."""
     import json
 
     import pathtracer_amd as pt

@@ -45,6 +45,19 @@ def test_noalloc_entry_matches_the_allocating_one_twice_in_a_row():
         g = got.cpu().numpy().view(pt.HIT_DTYPE)
         assert g.tobytes() == w.tobytes()
         assert (w["index"] != pt.MISS).mean() > 0.05
+    # the defining property: the call allocates nothing - device memory free / held by the handle do not move over
+    # repeated calls, also on a stream of the caller's own (what a capture would run on)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    free_before, held_before = torch.cuda.mem_get_info()[0], dev.memory()
+    for k in range(3):
+        got.fill_(0xCD)
+        torch.cuda.synchronize()  # (the fill runs on torch's stream, the call below on `side`)
+        dev.intersect_device_noalloc(d_rays.data_ptr(), n, got.data_ptr(), stream=side.cuda_stream if k else None)
+        side.synchronize()
+        torch.cuda.synchronize()
+        assert got.cpu().numpy().tobytes() == want.cpu().numpy().tobytes()
+    assert torch.cuda.mem_get_info()[0] == free_before and dev.memory() == held_before
     # a second handle on the same GPU shares the array (its address is per device, not per scene)
     other = scene.upload()
     other.intersect_device_noalloc(d_rays.data_ptr(), n, got.data_ptr())
