@@ -48,6 +48,8 @@ def test_noalloc_entry_matches_the_allocating_one_twice_in_a_row():
     # the defining property: the call allocates nothing - device memory free / held by the handle do not move over
     # repeated calls, also on a stream of the caller's own (what a capture would run on)
     side = torch.cuda.Stream()
+    dev.intersect_device_noalloc(d_rays.data_ptr(), n, got.data_ptr(), stream=side.cuda_stream)  # (the HIP runtime sets a
+    side.synchronize()                                                 # stream's own resources up at its first launch: 2 MiB)
     torch.cuda.synchronize()
     free_before, held_before = torch.cuda.mem_get_info()[0], dev.memory()
     for k in range(3):
