@@ -266,6 +266,9 @@ constexpr uint32_t TRI_BATCH_ANYHIT = PTX_TRI_BATCH_ANY;
 #ifndef PTX_ROUNDS
 #define PTX_ROUNDS 3  // (node steps, exit step) rounds per loop iteration before the triangle step is considered
 #endif
+#ifndef PTX_STATIC_UPTO
+#define PTX_STATIC_UPTO 8u  // launches with up to this many windows per wave hand half of them out without the cursor
+#endif
 #ifndef PTX_FORCE_LOBE
 #define PTX_FORCE_LOBE 0
 #endif
@@ -550,8 +553,20 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
         n_windows = n_a + (tail + 63u) / 64u;
     }
     const uint32_t n_pref = a.n_seg + 1u;  // entries of each prefix array of the plan
+    // Atomics on ONE address complete ~16 ns apart however many waves issue them (they are resolved at the memory side),
+    // and a launch has about four windows per wave whatever its size, so handing every window out through the cursor
+    // cost every launch 32 k x 16 ns = 0.5 ms - most of the time of the small late-bounce launches of a batch and all of
+    // config 1's (round 3, tools/launch_floor.py: a million camera rays took 200 us on cornell AND on cornell_teapot).
+    // So a wave takes its first windows by its own number - window wave + k * n_waves for k < n_own, no atomic: all of
+    // them when there are at most two per wave (the cursor is then never touched), half of them up to PTX_STATIC_UPTO
+    // per wave, and just the first one in the large launches, where the cursor is what keeps the waves even (three
+    // quarters by number cost cornell_teapot's camera launch 11 %: 29.0 -> 25.8 Grays/s).
+    const uint32_t per_wave = n_windows / n_waves;
+    const uint32_t n_own = per_wave <= 2u ? (n_windows + n_waves - 1u) / n_waves : (per_wave <= PTX_STATIC_UPTO ? per_wave / 2u : 1u);
+    const uint32_t n_static = n_own * n_waves;  // windows [0, n_static) are taken by number, [n_static, n_windows) from the cursor
     uint32_t lo = 0, hi = 0;
-    uint32_t windows = 0;  // 0: this wave has not taken its own first window yet, 1: it takes windows from the cursor, 2: no window is left
+    uint32_t windows = 0;  // 2: no window is left for this wave
+    uint32_t taken = 0;    // windows this wave has taken by its own number
     int32_t cur = DESC_IDLE;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, t_end = 0, t1 = 0, t2 = 0;
     constexpr uint32_t NO_RAY = 0xFFFFFFFFu;
@@ -596,20 +611,26 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
             if (lo >= hi) {
                 if (windows == 2u) break;
                 uint32_t w = 0;
-                // the first window of a wave is its own number, the later ones come from the launch's cursor (which
-                // counts from zero: + n_waves); a wave whose own number is past the last window never touches the
-                // cursor - on a small launch that is most of them, and 8192 waves x one device-scope atomic on one
-                // address, ~16 ns each, was the 0.13 ms an empty launch took
-                if (windows == 0u) {
-                    windows = 1u;
-                    w = wave_id;
+                // a wave's first n_own windows are wave + k * n_waves, the later ones come from the launch's cursor (which
+                // counts from zero: + n_static); a launch with at most two windows per wave never touches the cursor
+                if (taken < n_own) {
+                    w = wave_id + taken * n_waves;
+                    ++taken;
+                    if (w >= n_windows) {  // (only the last of a wave's own windows can lie past the end)
+                        windows = 2u;
+                        break;
+                    }
                 } else {
+                    if (n_static >= n_windows) {  // nothing was left for the cursor: it is never touched
+                        windows = 2u;
+                        break;
+                    }
                     if (lane == 0) w = atomicAdd(a.cursor, 1u);
-                    w = __builtin_amdgcn_readfirstlane(w) + n_waves;
-                }
-                if (w >= n_windows) {
-                    windows = 2u;
-                    break;
+                    w = __builtin_amdgcn_readfirstlane(w) + n_static;
+                    if (w >= n_windows) {
+                        windows = 2u;
+                        break;
+                    }
                 }
                 const bool large = w < n_a;
                 const uint32_t wl = large ? w : w - n_a;
