@@ -1046,7 +1046,6 @@ __global__ __launch_bounds__(BLOCK, PTX_SHADE_WAVES) void k_shade(DevScene sc, R
     const ptx_ray* __restrict__ rays_in = st.rays[q];
     ptx_ray* __restrict__ rays_out = st.rays[q ^ 1u];
     const uint32_t n_lights = NL ? (uint32_t)NL : sc.n_lights;
-    constexpr int MAXL = NL ? NL : PTX_MAX_LIGHTS;
     uint32_t parity = 0;
 
     // one workgroup per queue segment (see RenderState): read segment `seg`, write the survivors to the front
@@ -1064,7 +1063,28 @@ __global__ __launch_bounds__(BLOCK, PTX_SHADE_WAVES) void k_shade(DevScene sc, R
         bool emit_next = false, emit_shadow = false;
         uint32_t pid = 0, bounce = 1;
         V3 next_o = v3(0, 0, 0), next_d = v3(0, 0, 0), point_above = v3(0, 0, 0), T_old = v3(0, 0, 0), T_next = v3(0, 0, 0);
-        V3 sh_dir[MAXL], sh_c[MAXL];
+        // The lights are sampled AFTER the compaction barrier, one at a time, straight into the shadow queue: only what a
+        // sample needs - the point, the normal, the bsdf: 9 registers - crosses the barrier, not 6 registers per light
+        // (round 3: k_shade<4> 111 -> 76 VGPRs, 4 -> 6 waves per SIMD; sr2 3840x2160 shade -36 %, frame +18 %;
+        // cubesplosion shade -10 %; one light -1.5 %; profiles/r03_loop_variants.txt).
+        V3 sh_point = v3(0, 0, 0), sh_n = v3(0, 0, 0), sh_bsdf = v3(0, 0, 0);
+        // Light::sample_shadow_ray (light.rs:34-37,69-76), uniform_sample_unit_sphere (sampling.rs:9-17);
+        // emitted(&point) (light.rs:17-19), |wo . n| with wo = normalize(shadow dir) (pathtracer.rs:79-81)
+        auto light_sample = [&](uint32_t l, uint64_t key, uint32_t base, V3 point, V3 above, V3 n, V3 bsdf, V3& dir, V3& c) {
+            const ptx_light& L = sc.lights[l];
+            const float z = ptx_sym_open(key, base + 3u + 2u * l);
+            const float a = ptx_angle(key, base + 4u + 2u * l);
+            const float r = sqrtf(1.0f - z * z);
+            float sn, cs;
+            ptx_sincos(a, &sn, &cs);
+            const V3 center = v3(L.center[0], L.center[1], L.center[2]);
+            const V3 target = center + v3(r * cs, r * sn, z) * L.radius;
+            dir = target - above;
+            const V3 cp = center - point;
+            const V3 emitted = v3(L.intensity[0], L.intensity[1], L.intensity[2]) / dot(cp, cp);
+            const V3 wo = normalize(dir);
+            c = bsdf * emitted * fabsf(dot(wo, n));
+        };
         if (active) {
             const float4 ra = ld_stream(reinterpret_cast<const float4*>(rays_in) + 2 * (size_t)i);
             const float4 rb = ld_stream(reinterpret_cast<const float4*>(rays_in) + 2 * (size_t)i + 1);
@@ -1109,24 +1129,7 @@ __global__ __launch_bounds__(BLOCK, PTX_SHADE_WAVES) void k_shade(DevScene sc, R
                 if (!smp.is_delta && n_lights > 0) {
                     emit_shadow = true;
                     T_old = T;
-                    for (uint32_t l = 0; l < (NL ? (uint32_t)NL : n_lights); ++l) {
-                        // Light::sample_shadow_ray (light.rs:34-37,69-76), uniform_sample_unit_sphere (sampling.rs:9-17)
-                        const ptx_light& L = sc.lights[l];
-                        const float z = ptx_sym_open(key, base + 3u + 2u * l);
-                        const float a = ptx_angle(key, base + 4u + 2u * l);
-                        const float r = sqrtf(1.0f - z * z);
-                        float sn, cs;
-                        ptx_sincos(a, &sn, &cs);
-                        const V3 center = v3(L.center[0], L.center[1], L.center[2]);
-                        const V3 target = center + v3(r * cs, r * sn, z) * L.radius;
-                        const V3 dir = target - point_above;
-                        // emitted(&point) (light.rs:17-19), |wo . n| with wo = normalize(shadow dir) (pathtracer.rs:79-81)
-                        const V3 cp = center - point;
-                        const V3 emitted = v3(L.intensity[0], L.intensity[1], L.intensity[2]) / dot(cp, cp);
-                        const V3 wo = normalize(dir);
-                        sh_dir[l] = dir;
-                        sh_c[l] = smp.bsdf * emitted * fabsf(dot(wo, n));
-                    }
+                    sh_point = point, sh_n = n, sh_bsdf = smp.bsdf;
                 }
                 if (smp.pdf != 0.0f) {
                     const float cosine = dot(smp.wo, n);
@@ -1157,15 +1160,22 @@ __global__ __launch_bounds__(BLOCK, PTX_SHADE_WAVES) void k_shade(DevScene sc, R
         if (emit_shadow) {
             // one light: the record is the product k_resolve would form (0 + c == c, so T * (0 + c) == T * c
             // bit for bit) and no separate contribution array is written
-            if (NL == 1) st_stream(st.sh_T + slot_s, make_float4(T_old.x * sh_c[0].x, T_old.y * sh_c[0].y, T_old.z * sh_c[0].z, u2f(pid)));
-            else st_stream(st.sh_T + slot_s, make_float4(T_old.x, T_old.y, T_old.z, u2f(pid)));
+            if (NL != 1) st_stream(st.sh_T + slot_s, make_float4(T_old.x, T_old.y, T_old.z, u2f(pid)));
             if (st.sh_bounce) st.sh_bounce[slot_s] = (uint8_t)bounce;
+            // (the sampler key of the path again: cheaper than carrying it across the barrier)
+            const uint64_t key = ptx_path_key(st.seed, image_pixel(st, pid % st.n_pixels), st.first_sample + pid / st.n_pixels);
+            const uint32_t base = ptx_dim_base(bounce, n_lights);
+            V3 c0 = v3(0, 0, 0);  // one light: the contribution goes into the record below
             for (uint32_t l = 0; l < (NL ? (uint32_t)NL : n_lights); ++l) {
                 const size_t j = ((size_t)seg * n_lights + l) * st.seg_cap + (slot_s - seg_base);  // light-major (RenderState)
+                V3 dir, c;
+                light_sample(l, key, base, sh_point, point_above, sh_n, sh_bsdf, dir, c);
+                if (NL == 1) c0 = c;
                 st_stream(reinterpret_cast<float4*>(st.sh_rays) + 2 * j, make_float4(point_above.x, point_above.y, point_above.z, 0.0f));
-                st_stream(reinterpret_cast<float4*>(st.sh_rays) + 2 * j + 1, make_float4(sh_dir[l].x, sh_dir[l].y, sh_dir[l].z, 1.0f));
-                if (NL != 1) st_stream(st.sh_contrib + j, make_float4(sh_c[l].x, sh_c[l].y, sh_c[l].z, 0.0f));
+                st_stream(reinterpret_cast<float4*>(st.sh_rays) + 2 * j + 1, make_float4(dir.x, dir.y, dir.z, 1.0f));
+                if (NL != 1) st_stream(st.sh_contrib + j, make_float4(c.x, c.y, c.z, 0.0f));
             }
+            if (NL == 1) st_stream(st.sh_T + slot_s, make_float4(T_old.x * c0.x, T_old.y * c0.y, T_old.z * c0.z, u2f(pid)));
         }
     }
     n_next = regenerate(st, rays_out, st.transq[q ^ 1u], seg, n_next, started);  // fresh camera rays into the freed slots
