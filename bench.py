@@ -321,14 +321,19 @@ def kernel_figures(out, args, scene, dev, st, pinhole, base_sample, stream, W, H
 
     spp = args.spp_per_step
     ext_ms, sh_ms = st["extend_ms"], st["shadow_ms"]
-    out["extend_mrays_per_s"] = st["extend_rays"] / ext_ms / 1e3
+    # camera rays that miss the scene's bounding box end where they are generated (k_start) and never reach the extend
+    # kernel: they count as extend rays of the job (the reference traces them) but not in the kernel's rate
+    culled = st.get("culled_camera_rays", 0)
+    traversed = st["extend_rays"] - culled
+    out["culled_camera_rays"] = culled
+    out["extend_mrays_per_s"] = traversed / ext_ms / 1e3
     out["shadow_mrays_per_s"] = st["shadow_rays"] / sh_ms / 1e3 if sh_ms > 0 else None
     if st["extend_launches"] == args.steps * args.max_bounces:
         # no path regeneration: round r is bounce r, and every path shoots exactly one camera ray
         r_ext, _ = dev.round_times(args.max_bounces)
         camera_rays = float(args.steps) * W * H * spp
         if r_ext[0] > 0 and ext_ms > r_ext[0]:
-            out["extend_camera_mrays_per_s"] = camera_rays / r_ext[0] / 1e3
+            out["extend_camera_mrays_per_s"] = (camera_rays - culled) / r_ext[0] / 1e3
             out["extend_bounced_mrays_per_s"] = (st["extend_rays"] - camera_rays) / (ext_ms - r_ext[0]) / 1e3
     out["kernel_ms"] = {"extend": ext_ms, "shadow": sh_ms, "shade": st["shade_ms"], "generate": st["generate_ms"], "resolve_accumulate": st["other_ms"]}
     # Algorithmic bytes per extend ray: 32 ray + 16 hit + 8 per inner node + 40 per triangle test, node and
@@ -345,11 +350,12 @@ def kernel_figures(out, args, scene, dev, st, pinhole, base_sample, stream, W, H
         torch.cuda.synchronize()
         c = cdev.stats()
         cdev.close()
-        counted[label] = (c["extend_inner_nodes"] / max(c["extend_rays"], 1), c["extend_tri_tests"] / max(c["extend_rays"], 1))
+        c_rays = max(c["extend_rays"] - c.get("culled_camera_rays", 0), 1)  # rays the kernel traversed
+        counted[label] = (c["extend_inner_nodes"] / c_rays, c["extend_tri_tests"] / c_rays)
     b_ray_ref = 48.0 + 8.0 * counted["reference"][0] + 40.0 * counted["reference"][1]
     b_ray = 48.0 + 8.0 * counted["visited"][0] + 40.0 * counted["visited"][1]
     launches = st["extend_launches"]
-    rays_per_s = st["extend_rays"] / (ext_ms * 1e-3)
+    rays_per_s = traversed / (ext_ms * 1e-3)
     achieved = rays_per_s * b_ray / 1e9
     # with several sample batches in flight (ptx_set_pipelines > 1; the default is 1) launches of different
     # batches share the CUs and the per-launch durations above are inflated: repeat on one batch alone
@@ -363,7 +369,7 @@ def kernel_figures(out, args, scene, dev, st, pinhole, base_sample, stream, W, H
         dev.render_device(pinhole, min(spp, 64), tmp.data_ptr(), seed=0, first_sample=base_sample, stream=stream)
         torch.cuda.synchronize()
         ex = dev.stats()
-        ex_achieved = ex["extend_rays"] * b_ray / (ex["extend_ms"] * 1e-3) / 1e9
+        ex_achieved = (ex["extend_rays"] - ex.get("culled_camera_rays", 0)) * b_ray / (ex["extend_ms"] * 1e-3) / 1e9
     tr = measured_traffic(args.scene, args.size)
     hbm_per_ray = tr["extend_bytes_per_ray"] if tr else None
     out["roofline"] = {
@@ -375,7 +381,7 @@ def kernel_figures(out, args, scene, dev, st, pinhole, base_sample, stream, W, H
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
-        "traffic": hbm_per_ray * st["extend_rays"] / max(launches, 1) if hbm_per_ray else None,
+        "traffic": hbm_per_ray * traversed / max(launches, 1) if hbm_per_ray else None,
         "traffic_note": ("HBM bytes per launch = PMC bytes per ray (%s) x rays per launch" % tr["source"]) if tr
                         else "no PMC summary committed for this scene@size (profiles/hbm_traffic.json)",
         "limited_by": (tr or {}).get("limited_by", "VALU issue under divergence + dependent-load latency (see DESIGN.md 5); not HBM"),

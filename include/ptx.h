@@ -125,6 +125,8 @@ typedef struct ptx_counters {
     uint64_t extend_launches, shadow_launches; /* kernel launches of each traversal class */
     double extend_ms, shadow_ms, shade_ms, generate_ms, total_ms; /* only with PTX_FLAG_TIME_KERNELS */
     double other_ms; /* resolve + accumulate kernels */
+    uint64_t culled_camera_rays; /* of extend_rays: camera rays that miss the bounding box of the triangles and were finished
+                                    where they were generated (radiance = environment) instead of being queued and traversed */
 } ptx_counters;
 
 typedef struct ptx_scene ptx_scene; /* opaque: device-resident scene (one GPU) */

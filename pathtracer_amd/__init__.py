@@ -92,7 +92,7 @@ class Counters(C.Structure):
                 ("shadow_inner_nodes", C.c_uint64), ("shadow_tri_tests", C.c_uint64),
                 ("samples", C.c_uint64), ("extend_launches", C.c_uint64), ("shadow_launches", C.c_uint64),
                 ("extend_ms", C.c_double), ("shadow_ms", C.c_double), ("shade_ms", C.c_double),
-                ("generate_ms", C.c_double), ("total_ms", C.c_double), ("other_ms", C.c_double)]
+                ("generate_ms", C.c_double), ("total_ms", C.c_double), ("other_ms", C.c_double), ("culled_camera_rays", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

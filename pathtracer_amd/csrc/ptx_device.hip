@@ -110,6 +110,11 @@ struct RenderState {
     uint32_t n_pixels, n_samples, first_sample;  // n_pixels = pixels of the rendered region
     uint32_t reg_x, reg_y, reg_w;                // the region's corner and width inside the cam.width x cam.height image
     uint32_t tiles_per_row;                      // reg_w / 8 when local pixel numbers run over 8 x 8 tiles, else 0 (see image_pixel)
+    // Camera rays that cannot hit anything - they miss the (widened) bounding box of the triangles, box_clip() - are
+    // finished where they are generated: radiance = 0 + 1 * environment (pathtracer.rs:44-46 at the first bounce) and
+    // no queue entry.  They still count as extend rays (the reference traces them); totals[6] counts them separately.
+    uint32_t cull;
+    float box_lo[3], box_hi[3], env[3];
 };
 
 // ------------------------------------------------------------------------------------------ helpers
@@ -339,6 +344,40 @@ constexpr int NOALLOC_GRID = 256;  // workgroups of the allocation-free launch (
 constexpr size_t NOALLOC_SPILL_BYTES = (size_t)(PTX_MAX_DEPTH - LDS_DEPTH) * NOALLOC_GRID * TBLOCK * sizeof(uint2);
 constexpr size_t NOALLOC_SCRATCH_BYTES = 256 + NOALLOC_SPILL_BYTES;  // 34.0 MiB
 static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
+// The reference walks a ray's whole range [t_min, t_max] - [0, f32::MAX] for the renderer's rays - and so visits, and
+// tests the triangles of, every cell whose split planes the LINE crosses, also beyond the point where the ray has left
+// the scene.  A triangle can only be hit inside the bounding box of the triangles, so the range is narrowed to the ray's
+// passage through that box: the traversal then makes the same decisions on the part of the range that is left (the
+// split distances do not change), reaches every leaf whose segment of the ray meets the box, and accepts there what the
+// reference accepts.  The box is widened by a thousandth of the scene's extent, the slabs by 1e-5 of the ray's distance
+// to them and the range by 1e-4 of itself - four orders of magnitude more than the rounding of the reciprocal and of the
+// Moeller-Trumbore t, including for a ray that grazes a face of the box, where the widening of the box is divided by the
+// same small direction component that amplifies the rounding.  PTX_FLAG_NO_BOX_CLIP walks the full range (the counting
+// pass that prices the reference algorithm; tests compare the two hit for hit).
+// Narrows [t1, t_end] (t1 <= t_end on entry); returns false when nothing is left: the ray cannot hit anything.
+__device__ __forceinline__ bool box_clip(float ox, float oy, float oz, float dx, float dy, float dz, const float* box_lo, const float* box_hi,
+                                         float& t1, float& t_end) {
+    float te = t1, tx = t_end;
+#define PTX_SLAB(o, d, k)                                                         \
+    {                                                                             \
+        const float inv = __builtin_amdgcn_rcpf(d);                               \
+        const float wl = box_lo[k] - o, wh = box_hi[k] - o;                       \
+        const float pad = 1.0e-5f * fmaxf(fabsf(wl), fabsf(wh));                  \
+        const float ta = (wl - pad) * inv, tb = (wh + pad) * inv;                 \
+        te = fmaxf(te, fminf(ta, tb)); /* a NaN (0 * inf) leaves the bound alone */ \
+        tx = fminf(tx, fmaxf(ta, tb));                                            \
+    }
+    PTX_SLAB(ox, dx, 0)
+    PTX_SLAB(oy, dy, 1)
+    PTX_SLAB(oz, dz, 2)
+#undef PTX_SLAB
+    te = te - fabsf(te) * 1.0e-4f;
+    tx = tx + fabsf(tx) * 1.0e-4f;
+    if (te > t1) t1 = te;
+    if (tx < t_end) t_end = tx;
+    return t1 <= t_end;
+}
 
 // Windows.  A traversal launch hands its rays out in WINDOWS of one queue segment: `chunk` rays (a power of two in
 // [64, PTX_MAX_CHUNK], about four windows per wave over the launch), all of them first, segment-major, so that
@@ -671,37 +710,12 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                 dx = rb.x, dy = rb.y, dz = rb.z, t2 = t_end = a.internal ? 3.402823466e+38f : rb.w;
                 cur = a.root;
                 if (a.clip && t1 <= t_end) {  // (a window that is empty or NaN is walked as the reference walks it)
-                    // The reference walks the ray's whole range [t_min, t_max] - [0, f32::MAX] for the renderer's rays -
-                    // and so visits, and tests the triangles of, every cell whose split planes the LINE crosses, also
-                    // beyond the point where the ray has left the scene.  A triangle can only be hit inside the
-                    // bounding box of the triangles, so the range is narrowed to the ray's passage through that box:
-                    // the traversal then makes the same decisions on the part of the range that is left (the split
-                    // distances do not change), reaches every leaf whose segment of the ray meets the box, and accepts
-                    // there what the reference accepts.  The box is widened by a thousandth of the scene's extent,
-                    // the slabs by 1e-5 of the ray's distance to them and the range by 1e-4 of itself - four orders
-                    // of magnitude more than the rounding of the reciprocal and of the Moeller-Trumbore t, including
-                    // for a ray that grazes a face of the box, where the widening of the box is divided by the same small
-                    // direction component that amplifies the rounding.  PTX_FLAG_NO_BOX_CLIP walks the full range
-                    // (the counting pass that prices the reference algorithm; tests compare the two hit for hit).
-                    float te = t1, tx = t_end;
-#define PTX_SLAB(o, d, k)                                                         \
-    {                                                                             \
-        const float inv = __builtin_amdgcn_rcpf(d);                               \
-        const float wl = a.box_lo[k] - o, wh = a.box_hi[k] - o;                   \
-        const float pad = 1.0e-5f * fmaxf(fabsf(wl), fabsf(wh));                  \
-        const float ta = (wl - pad) * inv, tb = (wh + pad) * inv;                 \
-        te = fmaxf(te, fminf(ta, tb)); /* a NaN (0 * inf) leaves the bound alone */ \
-        tx = fminf(tx, fmaxf(ta, tb));                                            \
-    }
-                    PTX_SLAB(ox, dx, 0)
-                    PTX_SLAB(oy, dy, 1)
-                    PTX_SLAB(oz, dz, 2)
-#undef PTX_SLAB
-                    te = te - fabsf(te) * 1.0e-4f;
-                    tx = tx + fabsf(tx) * 1.0e-4f;
-                    if (te > t1) t1 = te;
-                    if (tx < t_end) t2 = t_end = tx;
-                    if (!(t1 <= t_end)) cur = DESC_EXIT;  // the ray misses the box: done at the next exit step (empty stack)
+                    // narrow the range to the ray's passage through the box of the triangles (box_clip above)
+                    float lo_t = t1, hi_t = t_end;
+                    const bool meets = box_clip(ox, oy, oz, dx, dy, dz, a.box_lo, a.box_hi, lo_t, hi_t);
+                    t1 = lo_t;
+                    t2 = t_end = hi_t;
+                    if (!meets) cur = DESC_EXIT;  // the ray misses the box: done at the next exit step (empty stack)
                 }
                 so = so0 + LVL;
                 ev = so0;
@@ -838,43 +852,76 @@ __device__ inline uint32_t image_pixel(const RenderState& st, uint32_t local) {
     return (st.reg_y + local / st.reg_w) * st.cam.width + st.reg_x + local % st.reg_w;
 }
 
-// sample_ray_for_pixel (pathtracer.rs:113-117) + Pinhole::ray (camera.rs:88-93): starts path `pid` in queue
-// slot `slot` and resets its state.
-__device__ inline void start_path(const RenderState& st, ptx_ray* __restrict__ rays, float4* __restrict__ trans, uint32_t slot,
-                                  uint32_t pid) {
+// sample_ray_for_pixel (pathtracer.rs:113-117) + Pinhole::ray (camera.rs:88-93): the camera ray of path `pid`.
+__device__ inline void camera_ray(const RenderState& st, uint32_t pid, float& dx, float& dy, float& dz) {
     const uint32_t pixel = image_pixel(st, pid % st.n_pixels), s = pid / st.n_pixels;
     const uint32_t px = pixel % st.cam.width, py = pixel / st.cam.width;
     const uint64_t key = ptx_path_key(st.seed, pixel, st.first_sample + s);
     const float cx = (float)px + ptx_u01(key, 0), cy = (float)py + ptx_u01(key, 1);
     const float u = cx / (float)st.cam.width, v = cy / (float)st.cam.height;
-    const float dx = st.cam.plane[0] + u * st.cam.dx[0] + v * st.cam.dy[0];
-    const float dy = st.cam.plane[1] + u * st.cam.dx[1] + v * st.cam.dy[1];
-    const float dz = st.cam.plane[2] + u * st.cam.dx[2] + v * st.cam.dy[2];
+    dx = st.cam.plane[0] + u * st.cam.dx[0] + v * st.cam.dy[0];
+    dy = st.cam.plane[1] + u * st.cam.dx[1] + v * st.cam.dy[1];
+    dz = st.cam.plane[2] + u * st.cam.dx[2] + v * st.cam.dy[2];
+}
+
+// Starts path `pid` in queue slot `slot` and resets its state.
+__device__ inline void start_path(const RenderState& st, ptx_ray* __restrict__ rays, uint32_t slot, uint32_t pid, float dx, float dy, float dz) {
     reinterpret_cast<float4*>(rays)[2 * (size_t)slot] = make_float4(st.cam.position[0], st.cam.position[1], st.cam.position[2], u2f(pid));
     reinterpret_cast<float4*>(rays)[2 * (size_t)slot + 1] = make_float4(dx, dy, dz, u2f(1u));
-    (void)trans;  // a path starts with transport (1, 1, 1): k_shade knows that from the bounce number, nothing is stored
+    // (a path starts with transport (1, 1, 1): k_shade knows that from the bounce number, nothing is stored)
     st.radiance[pid] = Rad{0.0f, 0.0f, 0.0f};
 }
 
 // Tops segment `seg` of `rays` (holding `have` entries) up with the next unstarted paths of its range.
-// All threads of the workgroup call; returns the new entry count.
-__device__ inline uint32_t regenerate(const RenderState& st, ptx_ray* __restrict__ rays, float4* __restrict__ trans, uint32_t seg,
-                                      uint32_t have, uint32_t started) {
+// All threads of the workgroup call; returns the new entry count and, in `begun`, the number of paths started (with
+// st.cull some of them end at once and take no entry).  lds / parity: the scratch of block_prefix2.
+__device__ inline uint32_t regenerate(const RenderState& st, ptx_ray* __restrict__ rays, uint32_t seg, uint32_t have, uint32_t started,
+                                      uint32_t* lds, uint32_t& parity, uint32_t& begun) {
     const uint32_t range_lo = seg * st.seg_range;
     const uint32_t range_n = range_lo >= st.n_paths ? 0u : (st.n_paths - range_lo < st.seg_range ? st.n_paths - range_lo : st.seg_range);
     const uint32_t room = st.seg_cap - have, left = range_n - started;
     const uint32_t k = room < left ? room : left;
-    for (uint32_t j = threadIdx.x; j < k; j += BLOCK) start_path(st, rays, trans, seg * st.seg_cap + have + j, range_lo + started + j);
+    begun = k;
     if (threadIdx.x == 0) st.seg_next[seg] = started + k;
-    return have + k;
+    if (!st.cull) {
+        for (uint32_t j = threadIdx.x; j < k; j += BLOCK) {
+            float dx, dy, dz;
+            camera_ray(st, range_lo + started + j, dx, dy, dz);
+            start_path(st, rays, seg * st.seg_cap + have + j, range_lo + started + j, dx, dy, dz);
+        }
+        return have + k;
+    }
+    uint32_t filled = have;
+    for (uint32_t j0 = 0; j0 < k; j0 += BLOCK) {
+        const uint32_t j = j0 + threadIdx.x, pid = range_lo + started + j;
+        bool enter = false;
+        float dx = 0, dy = 0, dz = 0;
+        if (j < k) {
+            camera_ray(st, pid, dx, dy, dz);
+            float t1 = 0.0f, t_end = 3.402823466e+38f;  // the renderer's range (pathtracer.rs:34)
+            enter = box_clip(st.cam.position[0], st.cam.position[1], st.cam.position[2], dx, dy, dz, st.box_lo, st.box_hi, t1, t_end);
+            if (!enter)  // accumulated_radiance (0) + accumulated_transport (1) * environment
+                st.radiance[pid] = Rad{0.0f + 1.0f * st.env[0], 0.0f + 1.0f * st.env[1], 0.0f + 1.0f * st.env[2]};
+        }
+        uint32_t pre, pre_unused, tot, tot_unused;
+        block_prefix2<WAVES>(enter, false, lds, parity, pre, pre_unused, tot, tot_unused);
+        parity ^= 1u;
+        if (enter) start_path(st, rays, seg * st.seg_cap + filled + pre, pid, dx, dy, dz);
+        filled += tot;
+    }
+    if (threadIdx.x == 0 && have + k != filled) atomicAdd(st.totals + 6, (unsigned long long)(have + k - filled));
+    return filled;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_start(RenderState st) {
+    __shared__ uint32_t lds[4 * WAVES];
+    uint32_t parity = 0;
     for (uint32_t seg = blockIdx.x; seg < st.n_seg; seg += gridDim.x) {
-        const uint32_t n = regenerate(st, st.rays[0], st.transq[0], seg, 0u, 0u);
+        uint32_t begun;
+        const uint32_t n = regenerate(st, st.rays[0], seg, 0u, 0u, lds, parity, begun);
         if (threadIdx.x == 0) {
             st.seg_ext[0][seg] = n;
-            if (n) atomicAdd(st.qcounts, n);
+            if (begun) atomicAdd(st.qcounts, begun);  // every camera ray counts, also the ones that ended here
         }
     }
 }
@@ -1052,10 +1099,8 @@ __global__ __launch_bounds__(BLOCK, PTX_SHADE_WAVES) void k_shade(DevScene sc, R
     // of segment `seg` of the output queues
     for (uint32_t seg = blockIdx.x; seg < st.n_seg; seg += gridDim.x) {
     const uint32_t count = st.seg_ext[q][seg];
-    const uint32_t started = st.seg_next[seg];
     const uint32_t seg_base = seg * st.seg_cap;
     uint32_t n_next = 0, n_shadow = 0;
-    __syncthreads();  // everybody has read seg_next before thread 0 rewrites it below
     for (uint32_t start = 0; start < count; start += BLOCK) {
         const bool active = start + threadIdx.x < count;
         // entry of this lane: in queue order, or (material-keyed queues) in the order k_bucket laid down
@@ -1178,7 +1223,7 @@ __global__ __launch_bounds__(BLOCK, PTX_SHADE_WAVES) void k_shade(DevScene sc, R
             if (NL == 1) st_stream(st.sh_T + slot_s, make_float4(T_old.x * c0.x, T_old.y * c0.y, T_old.z * c0.z, u2f(pid)));
         }
     }
-    n_next = regenerate(st, rays_out, st.transq[q ^ 1u], seg, n_next, started);  // fresh camera rays into the freed slots
+    // (a batch with more paths than queue slots tops the segment up with fresh camera rays next: k_regenerate)
     if (threadIdx.x == 0) {
         st.seg_ext[q ^ 1u][seg] = n_next;
         st.seg_sh[seg] = n_shadow;
@@ -1186,6 +1231,25 @@ __global__ __launch_bounds__(BLOCK, PTX_SHADE_WAVES) void k_shade(DevScene sc, R
             atomicAdd(reinterpret_cast<unsigned long long*>(st.qcounts + 2u * round),
                       (unsigned long long)n_next | ((unsigned long long)n_shadow << 32));
     }
+    }
+}
+
+// Path regeneration (a batch with more paths than queue slots, see RenderState): after k_shade(round) every segment
+// starts the next paths of its range in the slots that have become free.  A kernel of its own, launched only for such
+// batches: inside k_shade the camera-ray code cost that kernel ten registers and a wave per SIMD.
+__global__ __launch_bounds__(BLOCK) void k_regenerate(RenderState st, uint32_t round /* 1-based: the round k_shade has just run */) {
+    __shared__ uint32_t lds[4 * WAVES];
+    uint32_t parity = 0;
+    const uint32_t q = round & 1u;  // the queue k_shade(round) wrote
+    for (uint32_t seg = blockIdx.x; seg < st.n_seg; seg += gridDim.x) {
+        const uint32_t have = st.seg_ext[q][seg], started = st.seg_next[seg];
+        __syncthreads();  // everybody has read the two before thread 0 rewrites them
+        uint32_t begun;
+        const uint32_t n = regenerate(st, st.rays[q], seg, have, started, lds, parity, begun);
+        if (threadIdx.x == 0) {
+            st.seg_ext[q][seg] = n;
+            if (begun) atomicAdd(st.qcounts + 2u * round, begun);  // extend rays of the next round (also the ones that ended at once)
+        }
     }
 }
 
@@ -1885,7 +1949,10 @@ static int scene_create_impl(const ptx_scene_desc* d, uint32_t flags, ptx_scene*
                         : L == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shade<4>, BLOCK, 0)
                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shade<0>, BLOCK, 0);
         if (oe != hipSuccess || per_cu < 1) per_cu = 4;
-        if (per_cu > 8) per_cu = 8;
+        // ... and six of them at most: with the 71 VGPRs of round 3 seven fit, and seven are slower than six (k_shade on
+        // cornell_teapot 301 vs 283 ms per three steps, cornell_textured 411 vs 366, sr2 equal; eight - one more than
+        // fit - 303 / 404 and sr2 +70 %: tools/r3_percu.sh, profiles/r03_loop_variants.txt)
+        if (per_cu > 6) per_cu = 6;
         if (const char* ev = getenv("PTX_SHADE_PER_CU")) per_cu = atoi(ev) > 0 ? atoi(ev) : per_cu;
         if (getenv("PTX_VERBOSE")) fprintf(stderr, "[ptx] k_shade blocks per CU: %d\n", per_cu);
         sc->shade_grid = prop.multiProcessorCount * per_cu;
@@ -2300,6 +2367,9 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         st.seg_cap = seg_cap;
         st.seg_range = seg_range;
         st.totals = sc->totals.p;
+        // (the ray log and the brute-force checker want every ray in the queue)
+        st.cull = sc->clip_box && !sc->raylog_cap && !(sc->flags & PTX_FLAG_CHECK_BRUTE) ? 1u : 0u;
+        for (int k = 0; k < 3; ++k) st.box_lo[k] = sc->box_lo[k], st.box_hi[k] = sc->box_hi[k], st.env[k] = sc->dev.env[k];
         st.cam = *cam;
         st.seed = seed;
         st.n_pixels = n_pixels;
@@ -2349,6 +2419,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
                 else if (L == 2) k_shade<2><<<sg, BLOCK, 0, stream>>>(sc->dev, st, b);
                 else if (L == 4) k_shade<4><<<sg, BLOCK, 0, stream>>>(sc->dev, st, b);
                 else k_shade<0><<<sg, BLOCK, 0, stream>>>(sc->dev, st, b);
+                if (seg_range > seg_cap && b < rounds) k_regenerate<<<sg, BLOCK, 0, stream>>>(st, b);
                 // both queues k_shade has just written: the shadow launch of this round, the extend launch of the next
                 k_plan<<<2, 1024, 0, stream>>>(PlanArgs{st.seg_ext[b & 1], n_seg, 1u, 1u, n_waves, 0u, b < rounds ? plan_ext : nullptr},
                                                PlanArgs{st.seg_sh, n_seg * L, L ? L : 1u, 1u, n_waves, 1u, L ? plan_sh : nullptr});
@@ -2532,6 +2603,7 @@ int ptx_stats(ptx_scene* sc, ptx_counters* out) {
     out->extend_tri_tests = t[3];
     out->shadow_inner_nodes = t[4];
     out->shadow_tri_tests = t[5];
+    out->culled_camera_rays = t[6];
     out->samples = sc->samples_done;
     out->extend_launches = sc->extend_launches;
     out->shadow_launches = sc->shadow_launches;

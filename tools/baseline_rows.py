@@ -67,7 +67,7 @@ def main():
             secs = time.perf_counter() - t0
             g = dev.stats()
             row["gpu"] = {"spp": gpu_spp, "seconds": secs, "samples_per_s": gpu_spp * w * h / secs,
-                          "extend_mrays_per_s": g["extend_rays"] / g["extend_ms"] / 1e3, "shadow_mrays_per_s": g["shadow_rays"] / g["shadow_ms"] / 1e3 if g["shadow_ms"] else None,
+                          "extend_mrays_per_s": (g["extend_rays"] - g.get("culled_camera_rays", 0)) / g["extend_ms"] / 1e3, "culled_camera_rays_per_sample": g.get("culled_camera_rays", 0) / (gpu_spp * w * h), "shadow_mrays_per_s": g["shadow_rays"] / g["shadow_ms"] / 1e3 if g["shadow_ms"] else None,
                           "extend_rays_per_sample": g["extend_rays"] / (gpu_spp * w * h), "shadow_rays_per_sample": g["shadow_rays"] / (gpu_spp * w * h),
                           "queue_bytes": dev.memory()}
             if "cpu" in row:
