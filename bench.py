@@ -221,14 +221,15 @@ def run_rank(args):
         elapsed = float(t.item())
 
     st = dev.stats()
-    counts = torch.tensor([st["extend_rays"], st["shadow_rays"], st["samples"]], dtype=torch.float64, device=where)
+    counts = torch.tensor([st["extend_rays"], st["shadow_rays"], st["samples"], st.get("culled_camera_rays", 0)], dtype=torch.float64, device=where)
     if use_dist:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-    extend_rays, shadow_rays, samples = (float(x) for x in counts.tolist())
+    extend_rays, shadow_rays, samples, culled_rays = (float(x) for x in counts.tolist())
 
     out = None
     if rank == 0:
         out = result_line(args, scene, world, elapsed, samples, extend_rays, shadow_rays, load_s)
+        out["culled_camera_rays"] = culled_rays  # of extend_rays: ended at generation (they miss the scene's box), all ranks
         out["config"]["sharding"] = "samples per GPU, one process per GPU, one RCCL reduce"
         if dryrun:
             out["dryrun"] = True
@@ -325,7 +326,6 @@ def kernel_figures(out, args, scene, dev, st, pinhole, base_sample, stream, W, H
     # kernel: they count as extend rays of the job (the reference traces them) but not in the kernel's rate
     culled = st.get("culled_camera_rays", 0)
     traversed = st["extend_rays"] - culled
-    out["culled_camera_rays"] = culled
     out["extend_mrays_per_s"] = traversed / ext_ms / 1e3
     out["shadow_mrays_per_s"] = st["shadow_rays"] / sh_ms / 1e3 if sh_ms > 0 else None
     if st["extend_launches"] == args.steps * args.max_bounces:

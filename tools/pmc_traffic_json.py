@@ -23,7 +23,7 @@ fetch, n1 = total(fetch_dir, "FETCH_SIZE", "k_traverse<false")
 write, n2 = total(write_dir, "WRITE_SIZE", "k_traverse<false")
 b = json.loads(open(bench_json).read().strip().splitlines()[-1])
 steps, warm = b["steps"], b["warmup"]
-rays = b["extend_rays"] * (steps + warm) / steps  # the profiler saw the warm-up step too
+rays = (b["extend_rays"] - b.get("culled_camera_rays", 0)) * (steps + warm) / steps  # rays the kernel traversed; the profiler saw the warm-up step too
 per_ray = (2 * fetch + write) * 1024 / rays
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 path = os.path.join(root, "profiles", "hbm_traffic.json")
