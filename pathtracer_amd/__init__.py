@@ -535,6 +535,11 @@ def render_multi(scenes, pinhole, sample_count, seed=0, first_sample=0, accum=No
     return accum
 
 
+def multi_shutdown():
+    """Destroys the RCCL communicators ptx_render_multi cached (ptx_multi_shutdown)."""
+    _check(lib().ptx_multi_shutdown())
+
+
 def multi_last_reduce_ms():
     ms = C.c_double()
     _check(lib().ptx_multi_last_reduce_ms(C.byref(ms)))

@@ -1464,7 +1464,7 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(RenderState st, float* __r
     }
 }
 
-// `ImageBuffer::to_rgb8` (image_buffer.rs:29-38) on the device: gamma 1/2.2, clamp, round, saturate; NaN -> 0.  The
+// `ImageBuffer::to_rgb8` (image_buffer.rs:29-38) on the device: gamma 1/2.2, clamp, round, saturate; NaN -> 255 (Rust's f32::min(NaN, 1.0) is 1.0).  The
 // power is taken in f64 and rounded once to f32, which is what a correctly rounded powf gives (the host entry point
 // uses libm's powf): 4 channel values per lane, one dword store.
 __global__ __launch_bounds__(256) void k_tonemap(const float* __restrict__ accum, size_t n, float inv, uint8_t* __restrict__ out) {
@@ -2259,8 +2259,8 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
     // Batches.  The last rays of a launch finish ~0.3 ms after its cursor drains, and the late bounces of a
     // batch are small launches that cannot fill the chip (measured at 1080^2: 64 / 128 / 256 / 448 samples per
     // batch = 1.0 / 1.26 / 1.35 / 1.45 G samples/s), so a batch should be as wide as possible.  Two budgets
-    // bound it: queue SLOTS (162 B each with one light; default: 60 % of the memory that was free when the scene
-    // was created; slot x light indices are 32-bit)
+    // bound it: queue SLOTS (162 B each with one light; default: half of the memory the scene could have at the time of
+    // the call, auto_queue_bytes(); slot x light indices are 32-bit)
     // and path ids (12 B of radiance each, < 2^31).  A batch with more paths than slots runs with path regeneration:
     // every queue segment starts the next paths of its range as earlier ones end (see RenderState), so all
     // launches but the last few stay slot-wide.

@@ -161,3 +161,32 @@ def test_overlapping_batch_calls_on_two_streams_are_serialised():
             assert h.cpu().numpy().tobytes() == w.tobytes()
         assert (d_occ.cpu().numpy().astype(bool) == (want[0]["index"] != pt.MISS)).all()
     dev.close()
+
+
+def test_distinct_gpus_rccl_equals_peer_fold_equals_one_gpu():
+    """The paths a one-GPU box cannot reach: one handle per DISTINCT GPU, summed with RCCL (`ncclCommInitAll` over the
+    devices, the grouped `ncclReduce`) and with the peer fold (`hipMemcpyPeerAsync` between devices).  Skipped unless
+    two devices are visible - until it has run, multi-GPU results are unverified (README.md)."""
+    n = min(pt.device_count(), 4)
+    if n < 2:
+        pytest.skip("needs at least two GPUs")
+    scene = pt.LoadedScene(os.path.join(SCENES, "cornell_textured.obj"), max_bounces=6)
+    ph = scene.pinhole(96, 64)
+    devs = [scene.upload(device=g) for g in range(n)]
+    total = 4 * n + 1
+    peer = pt.render_multi(devs, ph, total, seed=5, first_sample=3, reduce=pt.REDUCE_PEER)
+    # the peer fold is the left fold of the shards' own renders, in shard order: reproduce it on GPU 0 alone
+    acc = None
+    for g in range(n):
+        first, count = pt.shard_samples(3, total, n, g)
+        part = devs[0].render(ph, count, seed=5, first_sample=first)
+        acc = part if acc is None else acc + part
+    assert peer.tobytes() == acc.tobytes()
+    rccl = pt.render_multi(devs, ph, total, seed=5, first_sample=3, reduce=pt.REDUCE_RCCL)
+    assert np.allclose(rccl, peer, rtol=2e-6, atol=1e-6)  # same samples; the ring sums in another order
+    auto = pt.render_multi(devs, ph, total, seed=5, first_sample=3)
+    assert np.allclose(auto, peer, rtol=2e-6, atol=1e-6)
+    one = devs[0].render(ph, total, seed=5, first_sample=3)
+    assert np.allclose(one, peer, rtol=2e-6, atol=1e-6)
+    for d in devs:
+        d.close()
