@@ -280,6 +280,12 @@ constexpr uint32_t TRI_BATCH_ANYHIT = PTX_TRI_BATCH_ANY;
 #ifndef PTX_PIXEL_TILES
 #define PTX_PIXEL_TILES 1
 #endif
+#ifndef PTX_SEG_MIN_PATHS
+#define PTX_SEG_MIN_PATHS 16384ull
+#endif
+#ifndef PTX_SEG_ROUNDS
+#define PTX_SEG_ROUNDS 4
+#endif
 #ifndef PTX_AUTO_MEMORY_FRACTION
 #define PTX_AUTO_MEMORY_FRACTION 0.5
 #endif
@@ -1555,7 +1561,9 @@ struct ptx_scene {
     std::vector<std::unique_ptr<DevBuf<float>>> textures;
     DevScene dev{};
     int grid = 2048;
-    int shade_grid = 2048;  // k_shade needs more registers: its grid is sized by the occupancy it really gets
+    int shade_slots = 2048;  // k_shade workgroups resident at once: sized by the occupancy that kernel really gets
+    int seg_rounds = 1;
+    int shade_grid = 2048;   // most queue segments a batch may have (shade_slots x seg_rounds)
 
     // render state (allocated on first render, grown on demand)
     uint32_t batch_samples = 0;  // 0 = choose from the image size
@@ -1955,7 +1963,15 @@ static int scene_create_impl(const ptx_scene_desc* d, uint32_t flags, ptx_scene*
         if (per_cu > 6) per_cu = 6;
         if (const char* ev = getenv("PTX_SHADE_PER_CU")) per_cu = atoi(ev) > 0 ? atoi(ev) : per_cu;
         if (getenv("PTX_VERBOSE")) fprintf(stderr, "[ptx] k_shade blocks per CU: %d\n", per_cu);
-        sc->shade_grid = prop.multiProcessorCount * per_cu;
+        // Queue segments = workgroups of k_start / k_shade / k_resolve.  One per resident workgroup slot leaves a third of
+        // the slots idle on average (PMC, cornell_teapot: 4100 of 6144 waves resident - a workgroup that has finished its
+        // segment has nothing else to do until the slowest one ends), so a large batch is cut into PTX_SEG_ROUNDS times
+        // as many segments and the hardware dispatcher hands the later ones out as slots free up: k_shade -6 % at 4,
+        // -9 % at 8 on cornell_teapot, sr2 best at 3 (tools/r3_segrounds.sh).  A small batch keeps one segment per slot.
+        sc->seg_rounds = PTX_SEG_ROUNDS;
+        if (const char* ev = getenv("PTX_SEG_ROUNDS")) sc->seg_rounds = atoi(ev) > 0 && atoi(ev) <= 16 ? atoi(ev) : sc->seg_rounds;
+        sc->shade_slots = prop.multiProcessorCount * per_cu;
+        sc->shade_grid = sc->shade_slots * sc->seg_rounds;
     }
     sc->tgrid = prop.multiProcessorCount * PTX_BLOCKS_PER_CU;  // sized so that the LDS of a CU is filled
     sc->flags = flags;
@@ -2298,7 +2314,9 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         }
         // queue segments (see RenderState): one per k_shade workgroup; seg_range paths each, seg_cap of them live
         const uint64_t batch_paths = (uint64_t)S * n_pixels;
-        n_seg = (uint32_t)sc->shade_grid;
+        // (several rounds of segments only while a segment keeps PTX_SEG_MIN_PATHS paths; one per slot below that)
+        n_seg = (uint32_t)sc->shade_slots;
+        if (batch_paths / PTX_SEG_MIN_PATHS > n_seg) n_seg = (uint32_t)(batch_paths / PTX_SEG_MIN_PATHS < (uint64_t)sc->shade_grid ? batch_paths / PTX_SEG_MIN_PATHS : (uint64_t)sc->shade_grid);
         if ((batch_paths + 255) / 256 < n_seg) n_seg = (uint32_t)((batch_paths + 255) / 256);
         if (n_seg < 1) n_seg = 1;
         seg_range = (uint32_t)(((batch_paths + n_seg - 1) / n_seg + 63) / 64 * 64);  // whole waves / pixel tiles per segment
