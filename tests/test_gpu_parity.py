@@ -197,6 +197,47 @@ def test_render_accumulates_into_buffer_and_counts_rays():
     clip.close()
 
 
+@pytest.mark.parametrize("name", ["sr2", "cubesplosion"])
+def test_camera_rays_that_miss_the_box_end_at_generation_and_change_nothing(name):
+    """Open scenes: most camera rays miss the bounding box of the triangles and are finished by k_start / k_regenerate
+    (radiance = environment, no queue entry).  Same image and same ray counts as the oracle and as the full-range walk
+    (FLAG_NO_BOX_CLIP, which also switches the shortcut off), also with path regeneration over a small queue and in a
+    region; the ray log and the brute-force checker still see every ray."""
+    path = os.path.join(SCENES, name + ".obj")
+    w, h, spp = 160, 90, 3
+    ref = orc.Scene(path, max_bounces=6)
+    want, _, st = ref.render(w, h, threads=spp, iterations_per_thread=1, mode=1, seed=41, stats=True)
+    scene = pt.LoadedScene(path, max_bounces=6)
+    ph = scene.pinhole(w, h)
+    dev = scene.upload()
+    assert dev.render(ph, spp, seed=41).tobytes() == want.tobytes()
+    s = dev.stats()
+    assert s["extend_rays"] == st["extend_rays"] and s["shadow_rays"] == st["shadow_rays"]
+    assert 0.3 * w * h * spp < s["culled_camera_rays"] < w * h * spp  # most of the frame is sky
+    dev.set_queue_slots(64 * 40)  # far fewer slots than paths: k_regenerate starts (and culls) paths round after round
+    dev.stats_reset()
+    assert dev.render(ph, spp, seed=41).tobytes() == want.tobytes()
+    s2 = dev.stats()
+    assert s2["extend_rays"] == st["extend_rays"] and s2["culled_camera_rays"] == s["culled_camera_rays"]
+    dev.close()
+    full = scene.upload(flags=pt.FLAG_NO_BOX_CLIP)
+    assert full.render(ph, spp, seed=41).tobytes() == want.tobytes()
+    assert full.stats()["culled_camera_rays"] == 0 and full.stats()["extend_rays"] == st["extend_rays"]
+    full.close()
+    chk = scene.upload(flags=pt.FLAG_CHECK_BRUTE)  # the checker wants every ray in the queue
+    assert chk.render(ph, 1, seed=41).tobytes() == dev_render_one(scene, ph).tobytes()
+    checked, fails = chk.check_report()
+    assert chk.stats()["culled_camera_rays"] == 0 and checked == chk.stats()["extend_rays"] + chk.stats()["shadow_rays"]
+    chk.close()
+
+
+def dev_render_one(scene, ph):
+    dev = scene.upload()
+    img = dev.render(ph, 1, seed=41)
+    dev.close()
+    return img
+
+
 def test_sample_sharding_is_exact_on_gpu():
     """Two disjoint sample ranges rendered into separate device buffers sum to the same partial sums the
     oracle produces — what the RCCL reduce of parallel.render_sharded adds up."""
