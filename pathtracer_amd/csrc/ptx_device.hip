@@ -1091,6 +1091,52 @@ __global__ __launch_bounds__(BLOCK) void k_bucket(DevScene sc, RenderState st, u
     }
 }
 
+// Next-event estimation resolve of one queue segment: accumulated_radiance += accumulated_transport * sum over lights
+// of the unoccluded contributions, in MTL light order (pathtracer.rs:68-86).  One path per lane; the occlusion flags
+// come from the any-hit traversal launch over the shadow-ray queue.
+__device__ inline void resolve_segment(const RenderState& st, uint32_t seg, uint32_t n_lights) {
+    for (uint32_t k = threadIdx.x, count = st.seg_sh[seg]; k < count; k += BLOCK) {
+        const uint32_t i = seg * st.seg_cap + k;
+        const float4 T = ld_stream(st.sh_T + i);
+        const uint32_t pid = f2u(T.w);
+        if (n_lights == 1u) {  // k_shade<1> stored transport * contribution (sh_index == i with one light)
+            if (!st.sh_occ[i]) {
+                Rad R = st.radiance[pid];
+                R.x = R.x + T.x;
+                R.y = R.y + T.y;
+                R.z = R.z + T.z;
+                st.radiance[pid] = R;
+            }
+            continue;
+        }
+        V3 incoming = v3(0.0f, 0.0f, 0.0f);
+        for (uint32_t l = 0; l < n_lights; ++l) {
+            const size_t j = ((size_t)seg * n_lights + l) * st.seg_cap + k;
+            V3 c = v3(0.0f, 0.0f, 0.0f);
+            if (!st.sh_occ[j]) {
+                const float4 cc = st.sh_contrib[j];
+                c = v3(cc.x, cc.y, cc.z);
+            }
+            incoming = incoming + c;
+        }
+        Rad R = st.radiance[pid];
+        R.x = R.x + T.x * incoming.x;
+        R.y = R.y + T.y * incoming.y;
+        R.z = R.z + T.z * incoming.z;
+        st.radiance[pid] = R;
+    }
+}
+
+// The resolve of round b runs as the prologue of k_shade(b + 1), segment by segment (a path's radiance is only ever
+// touched by its own queue segment, so the order of the additions is the reference's); only the last round's resolve is
+// a launch of its own.  Same bytes, but the scattered read-modify-writes of a segment overlap with the streaming loads
+// of the workgroups next to it instead of being a kernel of nothing else: shade + resolve -4 ... -8 %, the frame +2.3 %
+// on cornell_teapot, +4.5 % on cornell_textured, +1.8 % on sr2 (round 3, profiles/r03_loop_variants.txt 10; VERDICT round
+// 2 proposed it, DESIGN round 2 had priced it at < 0.5 %).
+#ifndef PTX_RESOLVE_IN_SHADE
+#define PTX_RESOLVE_IN_SHADE 1
+#endif
+
 // One bounce of trace_ray (pathtracer.rs:33-108) for every entry of the current extend queue.
 template <int NL /* compile-time light count, 0 = read it from the scene */>
 __global__ __launch_bounds__(BLOCK, PTX_SHADE_WAVES) void k_shade(DevScene sc, RenderState st, uint32_t round /* 1-based */) {
@@ -1107,6 +1153,12 @@ __global__ __launch_bounds__(BLOCK, PTX_SHADE_WAVES) void k_shade(DevScene sc, R
     const uint32_t count = st.seg_ext[q][seg];
     const uint32_t seg_base = seg * st.seg_cap;
     uint32_t n_next = 0, n_shadow = 0;
+#if PTX_RESOLVE_IN_SHADE
+    if (round > 1u) {  // the light samples of the round before: a path's radiance is only ever touched by its own segment
+        resolve_segment(st, seg, n_lights);
+        __syncthreads();
+    }
+#endif
     for (uint32_t start = 0; start < count; start += BLOCK) {
         const bool active = start + threadIdx.x < count;
         // entry of this lane: in queue order, or (material-keyed queues) in the order k_bucket laid down
@@ -1259,42 +1311,9 @@ __global__ __launch_bounds__(BLOCK) void k_regenerate(RenderState st, uint32_t r
     }
 }
 
-// Next-event estimation resolve: accumulated_radiance += accumulated_transport * sum over lights of the
-// unoccluded contributions, in MTL light order (pathtracer.rs:68-86).  One path per lane; the occlusion
-// flags come from the any-hit traversal launch over the shadow-ray queue.
 __global__ __launch_bounds__(BLOCK) void k_resolve(RenderState st, uint32_t bounce, uint32_t n_lights) {
     (void)bounce;
-    for (uint32_t seg = blockIdx.x; seg < st.n_seg; seg += gridDim.x)
-    for (uint32_t k = threadIdx.x, count = st.seg_sh[seg]; k < count; k += BLOCK) {
-        const uint32_t i = seg * st.seg_cap + k;
-        const float4 T = ld_stream(st.sh_T + i);
-        const uint32_t pid = f2u(T.w);
-        if (n_lights == 1u) {  // k_shade<1> stored transport * contribution (sh_index == i with one light)
-            if (!st.sh_occ[i]) {
-                Rad R = st.radiance[pid];
-                R.x = R.x + T.x;
-                R.y = R.y + T.y;
-                R.z = R.z + T.z;
-                st.radiance[pid] = R;
-            }
-            continue;
-        }
-        V3 incoming = v3(0.0f, 0.0f, 0.0f);
-        for (uint32_t l = 0; l < n_lights; ++l) {
-            const size_t j = ((size_t)seg * n_lights + l) * st.seg_cap + k;
-            V3 c = v3(0.0f, 0.0f, 0.0f);
-            if (!st.sh_occ[j]) {
-                const float4 cc = st.sh_contrib[j];
-                c = v3(cc.x, cc.y, cc.z);
-            }
-            incoming = incoming + c;
-        }
-        Rad R = st.radiance[pid];
-        R.x = R.x + T.x * incoming.x;
-        R.y = R.y + T.y * incoming.y;
-        R.z = R.z + T.z * incoming.z;
-        st.radiance[pid] = R;
-    }
+    for (uint32_t seg = blockIdx.x; seg < st.n_seg; seg += gridDim.x) resolve_segment(st, seg, n_lights);
 }
 
 // Checker (PTX_FLAG_CHECK_BRUTE): every ray of a queue again, against ALL triangles in index order
@@ -2473,7 +2492,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
                     if (sc->flags & PTX_FLAG_CHECK_BRUTE) launch_check(sc, st.sh_rays, sr, nullptr, st.sh_occ, sstream);
                     if (sc->raylog_cap) k_log<true><<<(int)n_seg, BLOCK, 0, sstream>>>(st, LogArgs{sc->raylog.p, sc->raylog_count.p, sc->raylog_cap}, 0u, L);
                 }
-                {
+                if (!PTX_RESOLVE_IN_SHADE || b == rounds) {
                     Timed tm(sc, sstream, KC_OTHER);
                     k_resolve<<<(int)n_seg, BLOCK, 0, sstream>>>(st, b, L);
                 }
