@@ -284,7 +284,7 @@ constexpr uint32_t TRI_BATCH_ANYHIT = PTX_TRI_BATCH_ANY;
 #define PTX_SEG_MIN_PATHS 16384ull
 #endif
 #ifndef PTX_SEG_ROUNDS
-#define PTX_SEG_ROUNDS 4
+#define PTX_SEG_ROUNDS 8
 #endif
 #ifndef PTX_AUTO_MEMORY_FRACTION
 #define PTX_AUTO_MEMORY_FRACTION 0.5
@@ -1985,8 +1985,10 @@ static int scene_create_impl(const ptx_scene_desc* d, uint32_t flags, ptx_scene*
         // Queue segments = workgroups of k_start / k_shade / k_resolve.  One per resident workgroup slot leaves a third of
         // the slots idle on average (PMC, cornell_teapot: 4100 of 6144 waves resident - a workgroup that has finished its
         // segment has nothing else to do until the slowest one ends), so a large batch is cut into PTX_SEG_ROUNDS times
-        // as many segments and the hardware dispatcher hands the later ones out as slots free up: k_shade -6 % at 4,
-        // -9 % at 8 on cornell_teapot, sr2 best at 3 (tools/r3_segrounds.sh).  A small batch keeps one segment per slot.
+        // as many segments and the hardware dispatcher hands the later ones out as slots free up.  With the resolve folded into
+        // k_shade (v26), 2 / 4 / 6 / 8 rounds: cornell_teapot 1864 / 1888 / 1910 / 1934 M samples/s, cornell_textured 2598 /
+        // 2654 / 2747 / 2762, cubesplosion 8036 / 8143 / 8278 / 8224, sr2 11700 / 11530 / 11698 / 11321 (its segments are
+        // mostly sky: smaller ones only add per-workgroup overhead) - tools/r3_envsweep.sh.  A small batch keeps one per slot.
         sc->seg_rounds = PTX_SEG_ROUNDS;
         if (const char* ev = getenv("PTX_SEG_ROUNDS")) sc->seg_rounds = atoi(ev) > 0 && atoi(ev) <= 16 ? atoi(ev) : sc->seg_rounds;
         sc->shade_slots = prop.multiProcessorCount * per_cu;
