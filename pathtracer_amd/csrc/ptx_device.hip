@@ -509,6 +509,7 @@ struct TravArgs {
     uint32_t fixed_count;
     uint32_t internal;  // rays of the renderer's own extend queue: t in [0, f32::MAX], w fields carry path id / bounce
     uint32_t clip;      // narrow every ray's t range to the bounding box of the triangles (see the refill)
+    uint32_t long_div;  // a split distance lies outside split_quotient()'s window: every ray is walked with the long division
     float box_lo[3], box_hi[3];  // that box, widened
     int32_t root;    // descriptor of the root
     ptx_hit* hits;   // nearest-hit output (ANY == false)
@@ -530,6 +531,44 @@ struct TravArgs {
 #define PTX_COUNT_SPILL_POP
 #define PTX_COUNT_SPILL_PUSH
 #endif
+// The split distance t = (dist - o) / d of a node visit (kdtree/src/lib.rs:113, aap.rs:44-51) must be the IEEE quotient:
+// it is compared with t1 / t2, becomes the t2 of the near segment and the t1 of the far one, and those decide which
+// triangle hits a leaf accepts.  The compiler's division (v_div_scale x 2, v_rcp, five fma, v_div_fmas, v_div_fixup) is
+// 12 of the node step's ~40 vector instructions.  The short form
+//     r = RN(1/d)  (v_rcp_f32, one Newton step),  q0 = RN(n r),  t = fma(fma(-d, q0, n), r, q0)
+// gives the same bits for EVERY pair of significands (tools/div_probe.hip: all 2^46 pairs, and 2^32 random pairs with
+// random signs and exponents, on the GPU: profiles/r03_div_probe.txt) as long as nothing overflows or underflows on the
+// way: with |d| in [2^-40, 2^10] and n = 0 or |n| in [2^-100, 2^61], r, q0 and t are normal and the remainder - a
+// multiple of 2^(exponent(n) - 47) - is exact.  short_div_ok() is that guard, taken once per ray: when the ray's origin
+// components and the tree's split distances are all 0 or in [2^-77, 2^60] in magnitude, n = dist - o is 0 or at least an
+// ulp of the smaller of the two; the direction components must be 0 (no division then) or in [2^-40, 2^10].  A ray that
+// fails it - NaN, infinities, denormals, 1e-13 in a direction - never enters the stepping loop: it is parked at the refill
+// and walked to its end right after it, in a plain loop with the compiler's division (PTX_WALK_LONG).  (The sign of a
+// zero quotient may differ between the two forms; t is only ever compared.)  What it buys (round 3, v28): 4.7 % fewer
+// vector instructions in the extend kernel, 5.1 % in the shadow kernel, and 1-2 % of their time - cornell_teapot +0.9 %,
+// sr2 +1.7 % of the frame (profiles/r03_loop_variants.txt 12): the kernel waits on its node and triangle loads for 60 %
+// of a wave's life, and instructions taken out of the node step shorten that chain only a little.
+__device__ __forceinline__ float split_quotient(float n, float d) {
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r0, 1.0f);
+    const float r = __builtin_fmaf(e, r0, r0);
+    const float q0 = n * r;
+    const float rem = __builtin_fmaf(-d, q0, n);
+    return __builtin_fmaf(rem, r, q0);
+}
+constexpr uint32_t DIV_POS_LO = (127u - 77u) << 23, DIV_POS_HI = (127u + 60u) << 23;  // origins, split distances
+constexpr uint32_t DIV_DIR_LO = (127u - 40u) << 23, DIV_DIR_HI = (127u + 10u) << 23;  // directions
+__host__ __device__ inline bool div_pos_ok(float x) {  // x is 0 or 2^-77 <= |x| <= 2^60
+    const uint32_t b = f2u(x) & 0x7FFFFFFFu;
+    return b - 1u >= DIV_POS_LO - 1u && b <= DIV_POS_HI;  // (0 - 1 wraps to the largest value)
+}
+__device__ __forceinline__ bool short_div_ok(float ox, float oy, float oz, float dx, float dy, float dz) {
+    const uint32_t o0 = f2u(ox) & 0x7FFFFFFFu, o1 = f2u(oy) & 0x7FFFFFFFu, o2 = f2u(oz) & 0x7FFFFFFFu;
+    const uint32_t d0 = f2u(dx) & 0x7FFFFFFFu, d1 = f2u(dy) & 0x7FFFFFFFu, d2 = f2u(dz) & 0x7FFFFFFFu;
+    const bool pos = min(min(o0 - 1u, o1 - 1u), o2 - 1u) >= DIV_POS_LO - 1u && max(max(o0, o1), o2) <= DIV_POS_HI;
+    const bool dir = min(min(d0 - 1u, d1 - 1u), d2 - 1u) >= DIV_DIR_LO - 1u && max(max(d0, d1), d2) <= DIV_DIR_HI;
+    return pos && dir;
+}
 #define PTX_EXIT_STEP \
             if (COUNT && __any(cur == DESC_EXIT)) pf_end_iter += lane == 0 ? 1u : 0u; \
             if (cur == DESC_EXIT) { \
@@ -553,14 +592,104 @@ struct TravArgs {
                 t2 = done ? t2 : u2f(tb); \
                 so = done ? so : st; \
             }
+// One node visit (kdtree/src/lib.rs:105-129) of the lanes that stand at an inner node; QUOT(n, d) is the division.
+// The top of the tree comes from LDS: no L1 tag lookup, a fifth of the latency.  The LDS read is written as an
+// instruction: as C++ the two loads are merged into one flat_load of a selected pointer, which goes through the
+// vector memory path for LDS addresses too.
+#define PTX_NODE_STEP(QUOT) \
+            if (cur >= 0) { \
+                uint4 nd; \
+                if (cur < top_n) { \
+                    u32x4 v; \
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(top_base + ((uint32_t)cur << 4)) : "memory"); \
+                    nd = make_uint4(v.x, v.y, v.z, v.w); \
+                } else { \
+                    nd = a.nodes[cur]; \
+                } \
+                if (COUNT) ++n_inner, ++pf_walk; \
+                const uint32_t axis = nd.y; \
+                const float dist = u2f(nd.x); \
+                const float da = pick(dx, dy, dz, axis); \
+                const float oa = pick(ox, oy, oz, axis); \
+                const float t = QUOT(dist - oa, da); /* unused (selected away) when da == 0 */ \
+                const bool fwd = da >= 0.0f; \
+                const uint32_t near_d = fwd ? nd.z : nd.w; \
+                const uint32_t far_d = fwd ? nd.w : nd.z; \
+                const bool parallel = da == 0.0f; \
+                const bool only_near = t > t2, only_far = t < t1; \
+                const bool push = !parallel && !only_near && !only_far; \
+                uint32_t next = only_far ? far_d : near_d; \
+                next = parallel ? (oa <= dist ? nd.z : nd.w) : next; \
+                if (push) { \
+                    if (so - ev > RING) { /* the ring is full: its oldest level sits in the slot this push takes */ \
+                        ev += LVL; \
+                        PTX_SPILL(ev) = PTX_SLOT(so); \
+                        PTX_COUNT_SPILL_PUSH \
+                    } \
+                    PTX_SLOT(so) = make_uint2(far_d, f2u(t)); \
+                    so += LVL; \
+                    t2 = t; \
+                } \
+                cur = (int32_t)next; \
+            }
+#define PTX_QUOT_LONG(n, d) ((n) / (d))
+#define PTX_QUOT_SHORT(n, d) split_quotient((n), (d))
+// The kernel's argument block as the refill reads it (see there).
+typedef __attribute__((address_space(4))) const TravArgs KernArgs;
+__device__ __forceinline__ KernArgs* kernargs() {
+    KernArgs* p = (KernArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+// One triangle of the leaf a lane waits in: geometry/src/geometry.rs:176-196.  The whole 48-byte record comes in one
+// go; the kind is its last word.
+#define PTX_TRI_STEP \
+                if (cur < -2) { \
+                    if (COUNT) ++pf_tri, ++n_tris; \
+                    TriRec rec; \
+                    { \
+                        const float4* rp = reinterpret_cast<const float4*>(a.tris + ((uint32_t)cur & DESC_PAYLOAD)); \
+                        const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2]; \
+                        __builtin_memcpy(&rec.f[0], &r0, 16); \
+                        __builtin_memcpy(&rec.f[4], &r1, 16); \
+                        __builtin_memcpy(&rec.f[8], &r2, 16); \
+                    } \
+                    const uint32_t tag = f2u(rec.f[10]); \
+                    const uint32_t idx = tag & DESC_PAYLOAD; \
+                    const bool last = (int32_t)tag < 0; \
+                    float t, u, v; \
+                    bool accept = false; \
+                    if (tri_test(rec, ox, oy, oz, dx, dy, dz, t, u, v) && t1 <= t && t <= t2) { \
+                        if (bi == PTX_MISS || !(bt <= t)) { /* the earlier triangle wins t ties */ \
+                            bt = t, bu = u, bv = v, bi = idx; \
+                            accept = true; \
+                        } \
+                    } \
+                    cur = (last || (ANY && accept)) ? DESC_EXIT : cur + 1; \
+                }
+// The answer of a lane that has finished its ray.  (Resolving here - radiance[path] += contribution for an unoccluded
+// shadow ray - was measured slower than the streaming resolve: the scattered read-modify-write stalls the whole wave.)
+#define PTX_WRITE_OUT \
+            { \
+                const auto* const kw = kernargs(); \
+                if (ANY) { \
+                    st_stream(kw->occ + ridx, (uint8_t)(bi != PTX_MISS ? 1 : 0)); \
+                } else { \
+                    st_stream(reinterpret_cast<uint4*>(kw->hits) + ridx, make_uint4(bi, f2u(bt), f2u(bu), f2u(bv))); \
+                } \
+                ridx = NO_RAY; \
+            }
 // Scalar registers count: two 1024-thread workgroups share a CU only while a wave's SGPR allocation stays at 80 or
 // below (measured in round 3: at 82 - the compiler still reports "occupancy 8" - half of the waves of a launch are
 // resident on average, SQ_WAVE_CYCLES x 4 / kernel cycles = 3840 instead of 7450, and every launch takes 1.45x as
 // long; capping the allocation with amdgpu_num_sgpr spills scalars into a 65th VGPR, which costs the same workgroup).
 // That is why the launch's uniform state is kept small: a segmented launch reads everything about its segments from
-// the plan (one pointer), and the Makefile checks the kernel's register counts after every build.
+// the plan (one pointer); what only the refill needs - the queue, the plan, the window arithmetic, the box, the outputs -
+// is read from the kernel's argument block there, through kernargs(), a pointer the compiler cannot see through, and so
+// does not stay in scalar registers across the stepping loop (76 -> 54 SGPRs, v28); and the Makefile checks the kernel's
+// register counts after every build.  The launch bounds say what the allocator must fit: 8 waves per SIMD, 64 VGPRs.
 template <bool ANY, bool COUNT>
-__global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
+__global__ __launch_bounds__(TBLOCK, 8) void k_traverse(TravArgs a) {
     // The traversal stack of a lane is a ring of LDS_DEPTH entries in LDS that always holds the NEWEST levels: when
     // a push finds the ring full, the oldest level it holds moves to the lane's column of a.spill (a store, off the
     // critical path), and a pop only reads global memory once the ring has run empty while older levels remain -
@@ -578,40 +707,14 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t gtid = blockIdx.x * TBLOCK + tid;
     const uint32_t so0 = RING - LVL + tid * 8u;  // off(0): level 1 lands in ring slot 0 of this lane's column
-    const bool segmented = a.plan != nullptr;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int32_t top_n = (int32_t)a.top_n;
     const uint32_t top_base = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint4*)s_top);
     for (uint32_t i = tid; i < a.top_n; i += TBLOCK) s_top[i] = a.nodes[i];
     __syncthreads();
-    // Windows (see k_plan): planned for a segmented launch, one segment's arithmetic otherwise.
-    const uint32_t n_waves = gridDim.x * (TBLOCK / 64);
-    const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (TBLOCK / 64) + (tid >> 6));
-    uint32_t chunk, n_a, n_windows, tail_num;
-    if (segmented) {
-        chunk = a.plan[0], n_a = a.plan[1], n_windows = n_a + a.plan[2], tail_num = a.plan[3];
-    } else {
-        const WinShape ws = win_shape(a.fixed_count, n_waves, ANY);
-        const uint32_t tail = win_tail(a.fixed_count, ws.tail_num);
-        chunk = ws.chunk, tail_num = ws.tail_num;
-        n_a = (a.fixed_count - tail + chunk - 1u) / chunk;
-        n_windows = n_a + (tail + 63u) / 64u;
-    }
-    const uint32_t n_pref = a.n_seg + 1u;  // entries of each prefix array of the plan
-    // Atomics on ONE address complete ~16 ns apart however many waves issue them (they are resolved at the memory side),
-    // and a launch has about four windows per wave whatever its size, so handing every window out through the cursor
-    // cost every launch 32 k x 16 ns = 0.5 ms - most of the time of the small late-bounce launches of a batch and all of
-    // config 1's (round 3, tools/launch_floor.py: a million camera rays took 200 us on cornell AND on cornell_teapot).
-    // So a wave takes its first windows by its own number - window wave + k * n_waves for k < n_own, no atomic: all of
-    // them when there are at most two per wave (the cursor is then never touched), half of them up to PTX_STATIC_UPTO
-    // per wave, and just the first one in the large launches, where the cursor is what keeps the waves even (three
-    // quarters by number cost cornell_teapot's camera launch 11 %: 29.0 -> 25.8 Grays/s).
-    const uint32_t per_wave = n_windows / n_waves;
-    const uint32_t n_own = per_wave <= 2u ? (n_windows + n_waves - 1u) / n_waves : (per_wave <= PTX_STATIC_UPTO ? per_wave / 2u : 1u);
-    const uint32_t n_static = n_own * n_waves;  // windows [0, n_static) are taken by number, [n_static, n_windows) from the cursor
     uint32_t lo = 0, hi = 0;
     uint32_t windows = 0;  // 2: no window is left for this wave
     uint32_t taken = 0;    // windows this wave has taken by its own number
+    constexpr int32_t DESC_PARKED = -3;  // a ray that waits for the long walk (no leaf descriptor: those end at 0xBFFFFFFD)
     int32_t cur = DESC_IDLE;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, t_end = 0, t1 = 0, t2 = 0;
     constexpr uint32_t NO_RAY = 0xFFFFFFFFu;
@@ -639,25 +742,47 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
 #endif
         // ---- write out the answers of the lanes that have finished since the last refill: once per refill
         // with many lanes, instead of inside the stepping loop whenever a single lane finishes
-        if (cur == DESC_IDLE && ridx != NO_RAY) {
-            if (ANY) {
-                // (resolving here - radiance[path] += contribution for an unoccluded ray - was measured slower
-                // than the separate streaming k_resolve: the scattered read-modify-write stalls the whole wave)
-                st_stream(a.occ + ridx, (uint8_t)(bi != PTX_MISS ? 1 : 0));
-            } else {
-                st_stream(reinterpret_cast<uint4*>(a.hits) + ridx, make_uint4(bi, f2u(bt), f2u(bu), f2u(bv)));
-            }
-            ridx = NO_RAY;
-        }
+        if (cur == DESC_IDLE && ridx != NO_RAY) PTX_WRITE_OUT
         // ---- refill idle lanes from the wave's window
         for (;;) {
             const unsigned long long idle = __ballot(cur == DESC_IDLE);
             if (!idle) break;
+            // Everything the refill needs of the launch - the queue, the plan, the box - is read from the kernel's argument
+            // block when it is needed (scalar loads through a pointer the compiler cannot see through) instead of living
+            // in scalar registers across the stepping loop: see "Scalar registers count" above.
+            const auto* const ka = kernargs();
             if (lo >= hi) {
                 if (windows == 2u) break;
+                // Windows (see k_plan): planned for a segmented launch, one segment's arithmetic otherwise.
+                const uint32_t* const plan = ka->plan;
+                const bool segmented = plan != nullptr;
+                const uint32_t fixed_count = ka->fixed_count;
+                const uint32_t n_waves = gridDim.x * (TBLOCK / 64);
+                const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (TBLOCK / 64) + (tid >> 6));
+                uint32_t chunk, n_a, n_windows, tail_num;
+                if (segmented) {
+                    chunk = plan[0], n_a = plan[1], n_windows = n_a + plan[2], tail_num = plan[3];
+                } else {
+                    const WinShape ws = win_shape(fixed_count, n_waves, ANY);
+                    const uint32_t tail = win_tail(fixed_count, ws.tail_num);
+                    chunk = ws.chunk, tail_num = ws.tail_num;
+                    n_a = (fixed_count - tail + chunk - 1u) / chunk;
+                    n_windows = n_a + (tail + 63u) / 64u;
+                }
+                const uint32_t n_pref = ka->n_seg + 1u;  // entries of each prefix array of the plan
+                // Atomics on ONE address complete ~16 ns apart however many waves issue them (they are resolved at the memory
+                // side), and a launch has about four windows per wave whatever its size, so handing every window out through
+                // the cursor cost every launch 32 k x 16 ns = 0.5 ms - most of the time of the small late-bounce launches of a
+                // batch and all of config 1's (round 3, tools/launch_floor.py: a million camera rays took 200 us on cornell AND
+                // on cornell_teapot).  So a wave takes its first windows by its own number - window wave + k * n_waves for
+                // k < n_own, no atomic: all of them when there are at most two per wave (the cursor is then never touched),
+                // half of them up to PTX_STATIC_UPTO per wave, and just the first one in the large launches, where the cursor
+                // is what keeps the waves even (three quarters by number cost cornell_teapot's camera launch 11 %: 29.0 ->
+                // 25.8 Grays/s).
+                const uint32_t per_wave = n_windows / n_waves;
+                const uint32_t n_own = per_wave <= 2u ? (n_windows + n_waves - 1u) / n_waves : (per_wave <= PTX_STATIC_UPTO ? per_wave / 2u : 1u);
+                const uint32_t n_static = n_own * n_waves;  // windows [0, n_static) are taken by number, [n_static, n_windows) from the cursor
                 uint32_t w = 0;
-                // a wave's first n_own windows are wave + k * n_waves, the later ones come from the launch's cursor (which
-                // counts from zero: + n_static); a launch with at most two windows per wave never touches the cursor
                 if (taken < n_own) {
                     w = wave_id + taken * n_waves;
                     ++taken;
@@ -670,7 +795,7 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                         windows = 2u;
                         break;
                     }
-                    if (lane == 0) w = atomicAdd(a.cursor, 1u);
+                    if (lane == 0) w = atomicAdd(ka->cursor, 1u);
                     w = __builtin_amdgcn_readfirstlane(w) + n_static;
                     if (w >= n_windows) {
                         windows = 2u;
@@ -683,7 +808,7 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                 if (segmented) {
                     // the segment of window wl: the largest s with pref[s] <= wl (pref[0] = 0, pref[n_seg] = all windows
                     // > wl; empty segments repeat their successor's value), by a 64-ary search with the whole wave
-                    const uint32_t* pref = a.plan + PLAN_HEADER + (large ? 0u : n_pref);
+                    const uint32_t* pref = plan + PLAN_HEADER + (large ? 0u : n_pref);
                     uint32_t span = n_pref, at = 0, at_val = 0;
                     while (span > 1u) {
                         const uint32_t step = (span + 63u) / 64u;
@@ -697,28 +822,34 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                     seg = __builtin_amdgcn_readfirstlane(at);
                     k = wl - at_val;
                 }
-                const uint32_t cnt = segmented ? a.plan[PLAN_HEADER + 2u * n_pref + seg] : a.fixed_count;
+                const uint32_t cnt = segmented ? plan[PLAN_HEADER + 2u * n_pref + seg] : fixed_count;
                 const uint32_t head = cnt - win_tail(cnt, tail_num);  // rays of this segment handed out in large windows
                 const uint32_t first = large ? k * chunk : head + k * 64u;
                 const uint32_t end = large ? head : cnt;
                 const uint32_t len = large ? chunk : 64u;
-                lo = seg * a.seg_cap + first;
-                hi = seg * a.seg_cap + (first + len < end ? first + len : end);
+                const uint32_t seg_cap = ka->seg_cap;
+                lo = seg * seg_cap + first;
+                hi = seg * seg_cap + (first + len < end ? first + len : end);
             }
-            const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));  // idle lanes below this one
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             const uint32_t avail = hi - lo;
             if (cur == DESC_IDLE && rank < avail) {
                 ridx = lo + rank;
-                const float4 ra = ld_stream(reinterpret_cast<const float4*>(a.rays) + 2 * (size_t)ridx);
-                const float4 rb = ld_stream(reinterpret_cast<const float4*>(a.rays) + 2 * (size_t)ridx + 1);
-                ox = ra.x, oy = ra.y, oz = ra.z, t1 = a.internal ? 0.0f : ra.w;
-                dx = rb.x, dy = rb.y, dz = rb.z, t2 = t_end = a.internal ? 3.402823466e+38f : rb.w;
-                cur = a.root;
-                if (a.clip && t1 <= t_end) {  // (a window that is empty or NaN is walked as the reference walks it)
+                const ptx_ray* const rays = ka->rays;
+                const bool internal = ka->internal != 0u;
+                const float4 ra = ld_stream(reinterpret_cast<const float4*>(rays) + 2 * (size_t)ridx);
+                const float4 rb = ld_stream(reinterpret_cast<const float4*>(rays) + 2 * (size_t)ridx + 1);
+                ox = ra.x, oy = ra.y, oz = ra.z, t1 = internal ? 0.0f : ra.w;
+                dx = rb.x, dy = rb.y, dz = rb.z, t2 = t_end = internal ? 3.402823466e+38f : rb.w;
+                cur = ka->root;
+                const bool odd = ka->long_div != 0u || !short_div_ok(ox, oy, oz, dx, dy, dz);  // outside split_quotient()'s window
+                if (ka->clip && t1 <= t_end) {  // (a window that is empty or NaN is walked as the reference walks it)
                     // narrow the range to the ray's passage through the box of the triangles (box_clip above)
                     float lo_t = t1, hi_t = t_end;
-                    const bool meets = box_clip(ox, oy, oz, dx, dy, dz, a.box_lo, a.box_hi, lo_t, hi_t);
+                    const float box_lo[3] = {ka->box_lo[0], ka->box_lo[1], ka->box_lo[2]};
+                    const float box_hi[3] = {ka->box_hi[0], ka->box_hi[1], ka->box_hi[2]};
+                    const bool meets = box_clip(ox, oy, oz, dx, dy, dz, box_lo, box_hi, lo_t, hi_t);
                     t1 = lo_t;
                     t2 = t_end = hi_t;
                     if (!meets) cur = DESC_EXIT;  // the ray misses the box: done at the next exit step (empty stack)
@@ -727,8 +858,24 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                 ev = so0;
                 bi = PTX_MISS;
                 bt = bu = bv = 0.0f;
+                if (odd && cur >= 0) cur = DESC_PARKED;  // walked below
             }
             lo += n_idle < avail ? n_idle : avail;
+        }
+        {
+            // PTX_WALK_LONG: while a parked ray is under way, EVERY live lane steps with the compiler's division (one node
+            // visit, one triangle, one leaf exit per pass - the long division is right for all of them); then back to the
+            // top, where the finished lanes write their answers and take new rays
+            const unsigned long long parked = __ballot(cur == DESC_PARKED);
+            if (parked) {
+                if (cur == DESC_PARKED) cur = kernargs()->root;
+                while (__ballot(cur != DESC_IDLE) & parked) {
+                    PTX_NODE_STEP(PTX_QUOT_LONG)
+                    PTX_TRI_STEP
+                    PTX_EXIT_STEP
+                }
+                continue;
+            }
         }
         if (__ballot(cur != DESC_IDLE) == 0ull) break;
         PTX_CLOCK(ck_refill)
@@ -745,43 +892,7 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
             if (round > 0) { PTX_EXIT_STEP }  // (the last round's exit step comes after the triangle step)
 #pragma unroll
             for (int node_sub = 0; node_sub < PTX_NODE_UNROLL; ++node_sub)
-            if (cur >= 0) {  // node visit, kdtree/src/lib.rs:105-129
-                uint4 nd;  // the top of the tree comes from LDS: no L1 tag lookup, a fifth of the latency
-                if (cur < top_n) {
-                    // written as an instruction: as C++ the two loads are merged into one flat_load of a
-                    // selected pointer, which goes through the vector memory path for LDS addresses too
-                    u32x4 v;
-                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(top_base + ((uint32_t)cur << 4)) : "memory");
-                    nd = make_uint4(v.x, v.y, v.z, v.w);
-                } else {
-                    nd = a.nodes[cur];
-                }
-                if (COUNT) ++n_inner, ++pf_walk;
-                const uint32_t axis = nd.y;
-                const float dist = u2f(nd.x);
-                const float da = pick(dx, dy, dz, axis);
-                const float oa = pick(ox, oy, oz, axis);
-                const float t = (dist - oa) / da;  // unused (selected away) when da == 0
-                const bool fwd = da >= 0.0f;
-                const uint32_t near_d = fwd ? nd.z : nd.w;
-                const uint32_t far_d = fwd ? nd.w : nd.z;
-                const bool parallel = da == 0.0f;
-                const bool only_near = t > t2, only_far = t < t1;
-                const bool push = !parallel && !only_near && !only_far;
-                uint32_t next = only_far ? far_d : near_d;
-                next = parallel ? (oa <= dist ? nd.z : nd.w) : next;
-                if (push) {
-                    if (so - ev > RING) {  // the ring is full: its oldest level sits in the slot this push takes
-                        ev += LVL;
-                        PTX_SPILL(ev) = PTX_SLOT(so);
-                        PTX_COUNT_SPILL_PUSH
-                    }
-                    PTX_SLOT(so) = make_uint2(far_d, f2u(t));
-                    so += LVL;
-                    t2 = t;
-                }
-                cur = (int32_t)next;
-            }
+            PTX_NODE_STEP(PTX_QUOT_SHORT)
             }
             PTX_CLOCK(ck_node)
             const unsigned long long in_leaf = __ballot(cur < -2);
@@ -790,29 +901,7 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
                 if (COUNT) pf_tri_iter += lane == 0 ? 1u : 0u;
 #pragma unroll
                 for (int tri_sub = 0; tri_sub < PTX_TRI_UNROLL; ++tri_sub)
-                if (cur < -2) {  // one triangle of the leaf: geometry/src/geometry.rs:176-196
-                    if (COUNT) ++pf_tri, ++n_tris;
-                    TriRec rec;  // the whole 48-byte record in one go; the kind is its last word
-                    {
-                        const float4* rp = reinterpret_cast<const float4*>(a.tris + ((uint32_t)cur & DESC_PAYLOAD));
-                        const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
-                        __builtin_memcpy(&rec.f[0], &r0, 16);
-                        __builtin_memcpy(&rec.f[4], &r1, 16);
-                        __builtin_memcpy(&rec.f[8], &r2, 16);
-                    }
-                    const uint32_t tag = f2u(rec.f[10]);
-                    const uint32_t idx = tag & DESC_PAYLOAD;
-                    const bool last = (int32_t)tag < 0;
-                    float t, u, v;
-                    bool accept = false;
-                    if (tri_test(rec, ox, oy, oz, dx, dy, dz, t, u, v) && t1 <= t && t <= t2) {
-                        if (bi == PTX_MISS || !(bt <= t)) {  // the earlier triangle wins t ties
-                            bt = t, bu = u, bv = v, bi = idx;
-                            accept = true;
-                        }
-                    }
-                    cur = (last || (ANY && accept)) ? DESC_EXIT : cur + 1;
-                }
+                PTX_TRI_STEP
             }
             PTX_CLOCK(ck_tri)
             PTX_EXIT_STEP
@@ -826,6 +915,9 @@ __global__ __launch_bounds__(TBLOCK) void k_traverse(TravArgs a) {
 #undef PTX_SLOT
 #undef PTX_SPILL
 #undef PTX_EXIT_STEP
+#undef PTX_NODE_STEP
+#undef PTX_TRI_STEP
+#undef PTX_WRITE_OUT
     if (COUNT) {
         wave_add(&a.work[0], n_inner);
         wave_add(&a.work[1], n_tris);
@@ -1572,6 +1664,7 @@ struct ptx_scene {
     uint32_t top_n = 0;  // inner nodes served from LDS
     bool clip_box = false;
     float box_lo[3] = {0, 0, 0}, box_hi[3] = {0, 0, 0};  // bounding box of the triangles, widened
+    bool long_div = false;  // a split distance outside split_quotient()'s window (or PTX_LONG_DIV=1)
     int tgrid = 1024;  // traversal workgroups (TBLOCK threads each)
     DevBuf<uint32_t> leaf_idx;
     DevBuf<TriRec> tris;
@@ -1861,6 +1954,7 @@ int launch_traverse(ptx_scene* sc, const ptx_ray* d_rays, const SegRange& sr, ui
     a.seg_cap = sr.cap;
     a.internal = sr.internal ? 1u : 0u;
     a.clip = sc->clip_box ? 1u : 0u;
+    a.long_div = sc->long_div ? 1u : 0u;
     for (int k = 0; k < 3; ++k) a.box_lo[k] = sc->box_lo[k], a.box_hi[k] = sc->box_hi[k];
     a.fixed_count = n;
     a.hits = d_hits;
@@ -2029,6 +2123,9 @@ static int scene_create_impl(const ptx_scene_desc* d, uint32_t flags, ptx_scene*
         sc->clip_box = true;
     }
     HIP_TRY(sc->nodes.upload(d->nodes, d->n_nodes));
+    for (uint32_t i = 0; i < d->n_nodes && !sc->long_div; ++i)
+        if ((d->nodes[i].w1 & 3u) != 3u && !div_pos_ok(u2f(d->nodes[i].w0))) sc->long_div = true;
+    if (const char* e = getenv("PTX_LONG_DIV")) sc->long_div = sc->long_div || atoi(e) != 0;  // A/B and tests
     {
         std::vector<DevNode> dn;
         std::vector<uint32_t> dl;

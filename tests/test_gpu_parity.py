@@ -347,3 +347,82 @@ def test_box_clip_changes_no_hit(name):
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
     h = np.frombuffer(out[0][0], pt.HIT_DTYPE)
     assert 0.05 < (h["index"] != 0xFFFFFFFF).mean() < 0.95  # the set exercises hits and misses
+
+
+def _odd_rays(lo, hi, n, seed):
+    """Synthetic rays of which every third has a component pushed outside the window in which k_traverse divides the
+    short way (ptx_device.hip: split_quotient / short_div_ok): origins 1e-30, denormal, 1e20, 3e38, infinite, NaN;
+    direction components 1e-15, denormal, 1e6 (unnormalised), infinite, NaN; and values exactly on the window's edges."""
+    rng = np.random.default_rng(seed)
+    rays = synthetic_rays(lo, hi, n, seed)
+    m = len(rays)
+    odd_o = np.array([1e-30, -1e-30, 1e-41, -3e-45, 1e20, -3e38, np.inf, -np.inf, np.nan, 2.0 ** -77, 2.0 ** -78, 2.0 ** 60, 2.0 ** 61], f32)
+    odd_d = np.array([1e-15, -1e-15, 1e-41, -1.4e-45, 1e6, -1e6, np.inf, np.nan, 2.0 ** -40, 2.0 ** -41, 2.0 ** 10, 2.0 ** 11, -0.0], f32)
+    pick = np.arange(0, m, 3)
+    which = rng.integers(0, 3, len(pick))
+    comp = rng.integers(0, 3, len(pick))
+    for k, (i, w, c) in enumerate(zip(pick, which, comp)):
+        if w == 0:
+            rays["o"][i, c] = odd_o[k % len(odd_o)]
+        elif w == 1:
+            rays["d"][i, c] = odd_d[k % len(odd_d)]
+        else:
+            rays["o"][i, c] = odd_o[(k // 3) % len(odd_o)]
+            rays["d"][i, (c + 1) % 3] = odd_d[(k // 5) % len(odd_d)]
+    return rays
+
+
+def _same_hits_nan_aware(got, want):
+    """Bit-exact, except that two NaNs in the same field count as equal whatever their payload."""
+    assert (got["index"] == want["index"]).all()
+    for f in ("t", "u", "v"):
+        g, w = got[f], want[f]
+        same = (g.view(np.uint32) == w.view(np.uint32)) | (np.isnan(g) & np.isnan(w))
+        assert same.all(), (f, int((~same).sum()), got[~same][:3], want[~same][:3])
+
+
+@pytest.mark.parametrize("name", ["cornell_teapot", "sr2"])
+def test_rays_outside_the_short_division_window_take_the_long_one(name, monkeypatch):
+    """The node step divides by multiplying with a refined reciprocal where that is proven to give the IEEE quotient
+    (tools/div_probe.hip) and with the compiler's division everywhere else.  Rays on either side of the guard, mixed
+    inside the same waves: hits equal the oracle's pointer-tree traversal (which always divides); and a library that
+    is told to divide the long way throughout (PTX_LONG_DIV=1) returns the same bytes as the default one."""
+    path = os.path.join(SCENES, name + ".obj")
+    ref = orc.Scene(path)
+    tris = ref.export()["triangles"].reshape(-1, 3, 3)
+    rays = _odd_rays(tris.min((0, 1)), tris.max((0, 1)), 1 << 17, 0x5EED0007)
+    want = ref.tree().intersect(rays, threads=8)
+    scene = pt.LoadedScene(path)
+    dev = scene.upload()
+    got = dev.intersect(rays)
+    _same_hits_nan_aware(got, want)
+    assert (got["index"] != pt.MISS).mean() > 0.1
+    plain = synthetic_rays(tris.min((0, 1)), tris.max((0, 1)), 1 << 18, 0x5EED0008)
+    short = dev.intersect(plain)
+    dev.close()
+    monkeypatch.setenv("PTX_LONG_DIV", "1")
+    dev = scene.upload()
+    assert dev.intersect(plain).tobytes() == short.tobytes()
+    assert dev.intersect(rays).tobytes() == got.tobytes()
+    dev.close()
+
+
+def test_scene_with_split_planes_outside_the_short_division_window():
+    """A tree with split planes outside the window (1e-30, a denormal, 2^61): the library sees it when the scene is
+    created and walks every ray with the long division.  Every leaf of the hand-made tree holds every triangle, so any
+    plane is a valid split.  (Whole scenes outside the window - coordinates around 1e-24 or 1e19 - are beyond what the
+    triangle tests can do in f32: their determinants underflow or overflow.)"""
+    rng = np.random.default_rng(11)
+    tris = rng.uniform(-1, 1, (12, 3, 3)).astype(f32)
+    tris[:4, :, 2] = tris[:4, :1, 2]  # four axis-aligned ones
+    every = L(*range(12))
+    spec = N(0, 1e-30, N(1, -1e-41, every, N(2, 0.25, every, every)), N(2, 2.0 ** 61, N(0, 0.5, every, every), every))
+    nodes, leaf = orc.flat_tree(spec)
+    lo, hi = np.array([-1, -1, -1], f32), np.array([1, 1, 1], f32)
+    rays = synthetic_rays(lo, hi, 1 << 16, 0x5EED0009)
+    want = orc.Tree.from_flat(tris.reshape(-1, 9), nodes, leaf).intersect(rays, threads=8)  # (axis-aligned ones as such)
+    dev = pt.DeviceScene.from_arrays(tris, nodes, leaf)
+    got = dev.intersect(rays)
+    dev.close()
+    assert_hits_equal(got, want)
+    assert (got["index"] != pt.MISS).mean() > 0.2
