@@ -596,16 +596,24 @@ __device__ __forceinline__ bool short_div_ok(float ox, float oy, float oz, float
 // The top of the tree comes from LDS: no L1 tag lookup, a fifth of the latency.  The LDS read is written as an
 // instruction: as C++ the two loads are merged into one flat_load of a selected pointer, which goes through the
 // vector memory path for LDS addresses too.
-#define PTX_NODE_STEP(QUOT) \
-            if (cur >= 0) { \
-                uint4 nd; \
-                if (cur < top_n) { \
+#define PTX_NODE_FROM_LDS(nd) \
+                { \
                     u32x4 v; \
                     asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(top_base + ((uint32_t)cur << 4)) : "memory"); \
                     nd = make_uint4(v.x, v.y, v.z, v.w); \
-                } else { \
-                    nd = a.nodes[cur]; \
-                } \
+                }
+#define PTX_NODE_STEP(QUOT) \
+            if (cur >= 0) { \
+                uint4 nd; \
+                if (cur < top_n) PTX_NODE_FROM_LDS(nd) else nd = a.nodes[cur]; \
+                PTX_NODE_BODY(QUOT) \
+            }
+// (Requesting BOTH children of a node below the LDS prefix as soon as it has arrived, so that the next visit finds its
+// node under way while this one is decided, was slower - extend +2.2 %, shadow +4 % on cornell_teapot, +2-3 % on sr2: half
+// again as many node loads through a vector memory path that is two-thirds busy cost more than the shorter wait saved;
+// profiles/r03_loop_variants.txt 13.)
+#define PTX_NODE_BODY(QUOT) \
+            { \
                 if (COUNT) ++n_inner, ++pf_walk; \
                 const uint32_t axis = nd.y; \
                 const float dist = u2f(nd.x); \
@@ -916,6 +924,8 @@ __global__ __launch_bounds__(TBLOCK, 8) void k_traverse(TravArgs a) {
 #undef PTX_SPILL
 #undef PTX_EXIT_STEP
 #undef PTX_NODE_STEP
+#undef PTX_NODE_BODY
+#undef PTX_NODE_FROM_LDS
 #undef PTX_TRI_STEP
 #undef PTX_WRITE_OUT
     if (COUNT) {
