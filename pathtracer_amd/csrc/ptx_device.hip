@@ -1295,6 +1295,14 @@ __global__ __launch_bounds__(BLOCK, PTX_SHADE_WAVES) void k_shade(DevScene sc, R
             const float4 rb = ld_stream(reinterpret_cast<const float4*>(rays_in) + 2 * (size_t)i + 1);
             pid = f2u(ra.w);
             bounce = f2u(rb.w);  // 1-based: the bounce this ray has just traced
+#ifdef PTX_SHADE_DUMMY  // probe: what do vector instructions cost this kernel?  (tools/r3_variants.sh)
+            {
+                float x = ra.x;
+#pragma unroll
+                for (int k = 0; k < PTX_SHADE_DUMMY; ++k) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(x));
+                if (x == 123.456f) bounce += 1u;
+            }
+#endif
             const uint32_t base = ptx_dim_base(bounce, n_lights);
             const uint4 hraw = ld_stream(reinterpret_cast<const uint4*>(st.hits) + i);
             // accumulated_transport = Vec3::ONE at the first bounce (pathtracer.rs:31): not stored by start_path
