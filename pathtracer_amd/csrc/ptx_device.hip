@@ -72,7 +72,7 @@ struct Rad {  // packed rgb: one dwordx3 per access
 struct RenderState {
     ptx_ray* rays[2];
     ptx_hit* hits;
-    float4* transq[2];  // accumulated transport of the entries of extend queue A / B (travels with the ray)
+    Rad* transq[2];     // accumulated transport of the entries of extend queue A / B (travels with the ray; 12 bytes)
     Rad* radiance;       // [path id] accumulated radiance of the sample (12 bytes)
     // Shadow entries of several lights are laid out LIGHT-MAJOR inside a queue segment: the entry of light l of the
     // segment's k-th shadow record sits at sh_index(seg, l, k) = (seg * n_lights + l) * seg_cap + k, so the rays of a
@@ -80,6 +80,8 @@ struct RenderState {
     // surface points (as coherent as camera rays) instead of holding 16 origins x 4 targets.  The traversal launch
     // sees n_seg * n_lights segments of seg_sh[seg] rays each.  k_resolve folds the lights in MTL order either way.
     ptx_ray* sh_rays;    // [sh_index] shadow ray: origin point_above, direction target - origin, t in [0,1]
+    // (24-byte shadow entries - the range [0, 1] is the same for every shadow ray and need not travel - take 3 % off k_shade
+    // and add as much to the shadow launch, whose refill then reads two arrays or unaligned entries: round 3, not kept.)
     float4* sh_T;        // [i] {transport before this bounce's update, bits(pid)}
     float4* sh_contrib;  // [sh_index] {bsdf * emitted * |cos|, 0}
     uint8_t* sh_occ;     // [sh_index] 1 = occluded
@@ -332,6 +334,21 @@ __device__ __forceinline__ void st_stream(uint4* p, uint4 v) {
     __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(p));
 #else
     *p = v;
+#endif
+}
+// 12-byte entries of a stream that is read and written front to back (the transport queues): three dwords, one instruction
+__device__ __forceinline__ void ld_stream3(const float* p, float& x, float& y, float& z) {
+#if PTX_STREAM_HINT
+    x = __builtin_nontemporal_load(p), y = __builtin_nontemporal_load(p + 1), z = __builtin_nontemporal_load(p + 2);
+#else
+    x = p[0], y = p[1], z = p[2];
+#endif
+}
+__device__ __forceinline__ void st_stream3(float* p, float x, float y, float z) {
+#if PTX_STREAM_HINT
+    __builtin_nontemporal_store(x, p), __builtin_nontemporal_store(y, p + 1), __builtin_nontemporal_store(z, p + 2);
+#else
+    p[0] = x, p[1] = y, p[2] = z;
 #endif
 }
 __device__ __forceinline__ void st_stream(uint8_t* p, uint8_t v) {
@@ -1308,8 +1325,7 @@ __global__ __launch_bounds__(BLOCK, PTX_SHADE_WAVES) void k_shade(DevScene sc, R
             // accumulated_transport = Vec3::ONE at the first bounce (pathtracer.rs:31): not stored by start_path
             V3 T = v3(1.0f, 1.0f, 1.0f);
             if (bounce != 1u) {
-                const float4 Traw = ld_stream(st.transq[q] + i);
-                T = v3(Traw.x, Traw.y, Traw.z);
+                ld_stream3(&st.transq[q][i].x, T.x, T.y, T.z);
             }
             if (hraw.x == PTX_MISS) {
                 // return accumulated_radiance + accumulated_transport * environment (pathtracer.rs:44-46)
@@ -1368,7 +1384,7 @@ __global__ __launch_bounds__(BLOCK, PTX_SHADE_WAVES) void k_shade(DevScene sc, R
         if (emit_next) {
             st_stream(reinterpret_cast<float4*>(rays_out) + 2 * (size_t)slot_n, make_float4(next_o.x, next_o.y, next_o.z, u2f(pid)));
             st_stream(reinterpret_cast<float4*>(rays_out) + 2 * (size_t)slot_n + 1, make_float4(next_d.x, next_d.y, next_d.z, u2f(bounce + 1u)));
-            st_stream(st.transq[q ^ 1u] + slot_n, make_float4(T_next.x, T_next.y, T_next.z, 0.0f));
+            st_stream3(&st.transq[q ^ 1u][slot_n].x, T_next.x, T_next.y, T_next.z);
         }
         if (emit_shadow) {
             // one light: the record is the product k_resolve would form (0 + c == c, so T * (0 + c) == T * c
@@ -1716,7 +1732,8 @@ struct ptx_scene {
         hipEvent_t ev_accum = nullptr, ev_join = nullptr;
         DevBuf<ptx_ray> rays[2];
         DevBuf<ptx_hit> hits;
-        DevBuf<float4> transq[2], sh_T, sh_contrib;
+        DevBuf<Rad> transq[2];
+        DevBuf<float4> sh_T, sh_contrib;
         DevBuf<Rad> radiance;
         DevBuf<ptx_ray> sh_rays;
         DevBuf<uint8_t> sh_occ, sh_bounce;
@@ -1893,7 +1910,7 @@ int grow_render_state(ptx_scene* sc, size_t slots, size_t paths, uint32_t rounds
             HIP_TRY(up->spill2.ensure((size_t)(PTX_MAX_DEPTH - LDS_DEPTH) * sc->tgrid * TBLOCK));
         }
         ptx_scene::Pipe& p = *up;
-        // per slot: 2 x 32 rays + 2 x 16 transport + 16 hit + 16 shadow record + 1 bounce, and per light
+        // per slot: 2 x 32 rays + 2 x 12 transport + 16 hit + 16 shadow record + 1 bounce, and per light
         // 32 shadow ray + 1 occlusion flag (+ 16 contribution when there are several lights)
         for (int q = 0; q < 2; ++q) {
             HIP_TRY(p.rays[q].ensure(slots));
@@ -2021,7 +2038,7 @@ uint64_t held_queue_bytes(const ptx_scene* sc) {
         if (!up) continue;
         const ptx_scene::Pipe& p = *up;
         b += (p.rays[0].n + p.rays[1].n + p.sh_rays.n) * sizeof(ptx_ray) + p.hits.n * sizeof(ptx_hit);
-        b += (p.transq[0].n + p.transq[1].n + p.sh_T.n + p.sh_contrib.n) * sizeof(float4) + p.radiance.n * sizeof(Rad);
+        b += (p.sh_T.n + p.sh_contrib.n) * sizeof(float4) + (p.transq[0].n + p.transq[1].n + p.radiance.n) * sizeof(Rad);
         b += p.perm.n * sizeof(uint32_t) + p.sh_occ.n + p.sh_bounce.n + (p.spill.n + p.spill2.n) * sizeof(uint2) + (p.counts.n + p.segs.n + p.plans.n) * sizeof(uint32_t);
     }
     return b;
@@ -2419,7 +2436,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
     const uint32_t n_pipes = sc->n_pipes;
     const uint32_t B = sc->dev.max_bounces, L = sc->dev.n_lights;
     // bytes per queue slot (see ensure_render_state) + the radiance of up to two paths per slot
-    const uint64_t slot_bytes = 129 + (uint64_t)(L ? L : 1u) * (33 + (L > 1 ? 16 : 0)) + 24;
+    const uint64_t slot_bytes = 121 + (uint64_t)(L ? L : 1u) * (33 + (L > 1 ? 16 : 0)) + 24;
     uint64_t slot_budget = (sc->slot_budget ? sc->slot_budget : auto_queue_bytes(sc) / slot_bytes) / n_pipes;
     // The automatic budget follows the free memory, which moves a little from call to call; queues that already
     // cover three quarters of it are kept as they are rather than rebuilt 1 % wider (a rebuild stalls the call:
