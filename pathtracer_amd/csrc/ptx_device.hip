@@ -83,7 +83,7 @@ struct RenderState {
     // (24-byte shadow entries - the range [0, 1] is the same for every shadow ray and need not travel - take 3 % off k_shade
     // and add as much to the shadow launch, whose refill then reads two arrays or unaligned entries: round 3, not kept.)
     float4* sh_T;        // [i] {transport before this bounce's update, bits(pid)}
-    float4* sh_contrib;  // [sh_index] {bsdf * emitted * |cos|, 0}
+    Rad* sh_contrib;     // [sh_index] bsdf * emitted * |cos| (12 bytes)
     uint8_t* sh_occ;     // [sh_index] 1 = occluded
     uint8_t* sh_bounce;  // [i] bounce of the path that shot the shadow rays; only while the ray log is on, else null
     uint32_t* perm;      // [slot] PTX_FLAG_MATERIAL_QUEUES: the order in which k_shade takes the entries of a segment (by material of the hit), else null
@@ -1233,7 +1233,7 @@ __device__ inline void resolve_segment(const RenderState& st, uint32_t seg, uint
             const size_t j = ((size_t)seg * n_lights + l) * st.seg_cap + k;
             V3 c = v3(0.0f, 0.0f, 0.0f);
             if (!st.sh_occ[j]) {
-                const float4 cc = st.sh_contrib[j];
+                const Rad cc = st.sh_contrib[j];
                 c = v3(cc.x, cc.y, cc.z);
             }
             incoming = incoming + c;
@@ -1402,7 +1402,7 @@ __global__ __launch_bounds__(BLOCK, PTX_SHADE_WAVES) void k_shade(DevScene sc, R
                 if (NL == 1) c0 = c;
                 st_stream(reinterpret_cast<float4*>(st.sh_rays) + 2 * j, make_float4(point_above.x, point_above.y, point_above.z, 0.0f));
                 st_stream(reinterpret_cast<float4*>(st.sh_rays) + 2 * j + 1, make_float4(dir.x, dir.y, dir.z, 1.0f));
-                if (NL != 1) st_stream(st.sh_contrib + j, make_float4(c.x, c.y, c.z, 0.0f));
+                if (NL != 1) st_stream3(&st.sh_contrib[j].x, c.x, c.y, c.z);
             }
             if (NL == 1) st_stream(st.sh_T + slot_s, make_float4(T_old.x * c0.x, T_old.y * c0.y, T_old.z * c0.z, u2f(pid)));
         }
@@ -1733,7 +1733,8 @@ struct ptx_scene {
         DevBuf<ptx_ray> rays[2];
         DevBuf<ptx_hit> hits;
         DevBuf<Rad> transq[2];
-        DevBuf<float4> sh_T, sh_contrib;
+        DevBuf<float4> sh_T;
+        DevBuf<Rad> sh_contrib;
         DevBuf<Rad> radiance;
         DevBuf<ptx_ray> sh_rays;
         DevBuf<uint8_t> sh_occ, sh_bounce;
@@ -1911,7 +1912,7 @@ int grow_render_state(ptx_scene* sc, size_t slots, size_t paths, uint32_t rounds
         }
         ptx_scene::Pipe& p = *up;
         // per slot: 2 x 32 rays + 2 x 12 transport + 16 hit + 16 shadow record + 1 bounce, and per light
-        // 32 shadow ray + 1 occlusion flag (+ 16 contribution when there are several lights)
+        // 32 shadow ray + 1 occlusion flag (+ 12 contribution when there are several lights)
         for (int q = 0; q < 2; ++q) {
             HIP_TRY(p.rays[q].ensure(slots));
             HIP_TRY(p.transq[q].ensure(slots));
@@ -2038,7 +2039,7 @@ uint64_t held_queue_bytes(const ptx_scene* sc) {
         if (!up) continue;
         const ptx_scene::Pipe& p = *up;
         b += (p.rays[0].n + p.rays[1].n + p.sh_rays.n) * sizeof(ptx_ray) + p.hits.n * sizeof(ptx_hit);
-        b += (p.sh_T.n + p.sh_contrib.n) * sizeof(float4) + (p.transq[0].n + p.transq[1].n + p.radiance.n) * sizeof(Rad);
+        b += p.sh_T.n * sizeof(float4) + (p.sh_contrib.n + p.transq[0].n + p.transq[1].n + p.radiance.n) * sizeof(Rad);
         b += p.perm.n * sizeof(uint32_t) + p.sh_occ.n + p.sh_bounce.n + (p.spill.n + p.spill2.n) * sizeof(uint2) + (p.counts.n + p.segs.n + p.plans.n) * sizeof(uint32_t);
     }
     return b;
@@ -2436,7 +2437,7 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
     const uint32_t n_pipes = sc->n_pipes;
     const uint32_t B = sc->dev.max_bounces, L = sc->dev.n_lights;
     // bytes per queue slot (see ensure_render_state) + the radiance of up to two paths per slot
-    const uint64_t slot_bytes = 121 + (uint64_t)(L ? L : 1u) * (33 + (L > 1 ? 16 : 0)) + 24;
+    const uint64_t slot_bytes = 121 + (uint64_t)(L ? L : 1u) * (33 + (L > 1 ? 12 : 0)) + 24;
     uint64_t slot_budget = (sc->slot_budget ? sc->slot_budget : auto_queue_bytes(sc) / slot_bytes) / n_pipes;
     // The automatic budget follows the free memory, which moves a little from call to call; queues that already
     // cover three quarters of it are kept as they are rather than rebuilt 1 % wider (a rebuild stalls the call:
