@@ -273,6 +273,12 @@ constexpr uint32_t TRI_BATCH_ANYHIT = PTX_TRI_BATCH_ANY;
 #ifndef PTX_ROUNDS
 #define PTX_ROUNDS 3  // (node steps, exit step) rounds per loop iteration before the triangle step is considered
 #endif
+#ifndef PTX_DRY_FLAG
+#define PTX_DRY_FLAG 1
+#endif
+#ifndef PTX_GRAB
+#define PTX_GRAB 2u  // windows per atomic in launches of up to PTX_STATIC_UPTO windows per wave
+#endif
 #ifndef PTX_STATIC_UPTO
 #define PTX_STATIC_UPTO 8u  // launches with up to this many windows per wave hand half of them out without the cursor
 #endif
@@ -284,6 +290,9 @@ constexpr uint32_t TRI_BATCH_ANYHIT = PTX_TRI_BATCH_ANY;
 #endif
 #ifndef PTX_SEG_MIN_PATHS
 #define PTX_SEG_MIN_PATHS 16384ull
+#endif
+#ifndef PTX_SEG_SMALL_PATHS
+#define PTX_SEG_SMALL_PATHS 1024ull
 #endif
 #ifndef PTX_SEG_ROUNDS
 #define PTX_SEG_ROUNDS 8
@@ -726,6 +735,7 @@ __global__ __launch_bounds__(TBLOCK, 8) void k_traverse(TravArgs a) {
     static_assert((LDS_DEPTH & (LDS_DEPTH - 1)) == 0 && (TBLOCK & (TBLOCK - 1)) == 0, "the ring needs powers of two");
     __shared__ uint2 s_stack[LDS_DEPTH][TBLOCK];
     __shared__ uint4 s_top[TOP_NODES > 0 ? TOP_NODES : 1];
+    __shared__ uint32_t s_dry;  // a wave of this workgroup has found the cursor's pool empty: the others need not ask
     char* const s_base = reinterpret_cast<char*>(&s_stack[0][0]);
     constexpr uint32_t LVL = TBLOCK * 8u;        // bytes per stack level
     constexpr uint32_t RING = LVL * LDS_DEPTH;   // bytes of the ring
@@ -735,10 +745,12 @@ __global__ __launch_bounds__(TBLOCK, 8) void k_traverse(TravArgs a) {
     const int32_t top_n = (int32_t)a.top_n;
     const uint32_t top_base = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint4*)s_top);
     for (uint32_t i = tid; i < a.top_n; i += TBLOCK) s_top[i] = a.nodes[i];
+    if (tid == 0) s_dry = 0u;
     __syncthreads();
     uint32_t lo = 0, hi = 0;
     uint32_t windows = 0;  // 2: no window is left for this wave
     uint32_t taken = 0;    // windows this wave has taken by its own number
+    uint32_t pend_next = 0, pend_end = 0;  // windows taken from the cursor several at a time and not yet used
     constexpr int32_t DESC_PARKED = -3;  // a ray that waits for the long walk (no leaf descriptor: those end at 0xBFFFFFFD)
     int32_t cur = DESC_IDLE;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, t_end = 0, t1 = 0, t2 = 0;
@@ -820,11 +832,30 @@ __global__ __launch_bounds__(TBLOCK, 8) void k_traverse(TravArgs a) {
                         windows = 2u;
                         break;
                     }
-                    if (lane == 0) w = atomicAdd(ka->cursor, 1u);
-                    w = __builtin_amdgcn_readfirstlane(w) + n_static;
-                    if (w >= n_windows) {
-                        windows = 2u;
-                        break;
+                    // A launch of a few windows per wave has them all under way at once, and what it then waits for is the
+                    // cursor (a 4 M-ray launch on cornell: 405 us, 393 of them 24 576 atomics; the late-bounce launches of the
+                    // 4K scenes sit on the same floor): there one atomic takes PTX_GRAB windows.  (Large launches keep single
+                    // windows: grabs of remaining / (4 x waves) windows cost cornell_teapot 15 % - the waves then work on
+                    // distant parts of the queue at the same time and share less of the tree in the L2.)
+                    if (pend_next < pend_end) {
+                        w = pend_next++;
+                    } else {
+                        // (the last atomic of a wave finds nothing: 8192 of them, ~16 ns apiece, at the end of every launch -
+                        // the first wave of a workgroup to see the pool empty says so, and the other fifteen do not ask)
+                        if (PTX_DRY_FLAG && *(volatile uint32_t*)&s_dry) {
+                            windows = 2u;
+                            break;
+                        }
+                        const uint32_t g = per_wave <= PTX_STATIC_UPTO ? PTX_GRAB : 1u;
+                        if (lane == 0) w = atomicAdd(ka->cursor, g);
+                        w = __builtin_amdgcn_readfirstlane(w) + n_static;
+                        if (w >= n_windows) {
+                            if (PTX_DRY_FLAG && lane == 0) *(volatile uint32_t*)&s_dry = 1u;
+                            windows = 2u;
+                            break;
+                        }
+                        pend_next = w + 1u;
+                        pend_end = w + g < n_windows ? w + g : n_windows;
                     }
                 }
                 const bool large = w < n_a;
@@ -2106,10 +2137,11 @@ static int scene_create_impl(const ptx_scene_desc* d, uint32_t flags, ptx_scene*
                         : L == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shade<4>, BLOCK, 0)
                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shade<0>, BLOCK, 0);
         if (oe != hipSuccess || per_cu < 1) per_cu = 4;
-        // ... and six of them at most: with the 71 VGPRs of round 3 seven fit, and seven are slower than six (k_shade on
-        // cornell_teapot 301 vs 283 ms per three steps, cornell_textured 411 vs 366, sr2 equal; eight - one more than
-        // fit - 303 / 404 and sr2 +70 %: tools/r3_percu.sh, profiles/r03_loop_variants.txt)
-        if (per_cu > 6) per_cu = 6;
+        // ... and as many as fit: eight since v30 (62 VGPRs without packed math; with the 69-71 VGPRs before, seven fitted and
+        // six were faster).  6 / 7 / 8, three alternating repetitions (tools/r3_env_ab.sh, profiles/r03_loop_variants.txt 16):
+        // cornell_teapot 1946 / 1953 / 1967 M samples/s, cornell_textured 2784 / 2823 / 2831, cubesplosion 8343 / 8471 / 8441,
+        // sr2 12184 / 12320 / 12171.
+        if (per_cu > 8) per_cu = 8;
         if (const char* ev = getenv("PTX_SHADE_PER_CU")) per_cu = atoi(ev) > 0 ? atoi(ev) : per_cu;
         if (getenv("PTX_VERBOSE")) fprintf(stderr, "[ptx] k_shade blocks per CU: %d\n", per_cu);
         // Queue segments = workgroups of k_start / k_shade / k_resolve.  One per resident workgroup slot leaves a third of
@@ -2471,6 +2503,10 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
         // (several rounds of segments only while a segment keeps PTX_SEG_MIN_PATHS paths; one per slot below that)
         n_seg = (uint32_t)sc->shade_slots;
         if (batch_paths / PTX_SEG_MIN_PATHS > n_seg) n_seg = (uint32_t)(batch_paths / PTX_SEG_MIN_PATHS < (uint64_t)sc->shade_grid ? batch_paths / PTX_SEG_MIN_PATHS : (uint64_t)sc->shade_grid);
+        // (a small batch: segments of about a thousand paths, one per CU at least - cornell 256 x 256, 16 spp with 2 / 3 / 4 /
+        // 5 / 6 / 8 segments per CU: 720 / 726 / 725 / 701 / 694 / 657 M samples/s)
+        const uint64_t cus = (uint64_t)(sc->tgrid / PTX_BLOCKS_PER_CU);
+        if (batch_paths / PTX_SEG_SMALL_PATHS < n_seg) n_seg = (uint32_t)(batch_paths / PTX_SEG_SMALL_PATHS > cus ? batch_paths / PTX_SEG_SMALL_PATHS : cus);
         if ((batch_paths + 255) / 256 < n_seg) n_seg = (uint32_t)((batch_paths + 255) / 256);
         if (n_seg < 1) n_seg = 1;
         seg_range = (uint32_t)(((batch_paths + n_seg - 1) / n_seg + 63) / 64 * 64);  // whole waves / pixel tiles per segment
