@@ -262,7 +262,7 @@ int ptx_intersect_batch_device(ptx_scene* scene, const ptx_ray* d_rays, size_t n
  * harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same kernel and same results; the work
  * cursor and the stack-spill area live in a file-scope device array of the library (34.0 MiB per GPU, held
  * until the process ends) instead of scene-owned allocations, and the call creates no event and takes no
- * timing stamp: it enqueues one 32-byte memset (the launch's cursor words) and one kernel on `stream`.  At most PTX_NOALLOC_MAX_RAYS rays
+ * timing stamp: it enqueues one 1-KB memset (the launch's cursor words) and one kernel on `stream`.  At most PTX_NOALLOC_MAX_RAYS rays
  * per call (PTX_E_LIMIT beyond).  All handles on one GPU share that array: calls that overlap on one GPU
  * (two streams, two handles, two threads) race - the caller orders them. */
 #define PTX_NOALLOC_MAX_RAYS (1u << 24)

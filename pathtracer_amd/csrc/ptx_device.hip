@@ -273,8 +273,8 @@ constexpr uint32_t TRI_BATCH_ANYHIT = PTX_TRI_BATCH_ANY;
 #ifndef PTX_ROUNDS
 #define PTX_ROUNDS 3  // (node steps, exit step) rounds per loop iteration before the triangle step is considered
 #endif
-#ifndef PTX_DRY_FLAG
-#define PTX_DRY_FLAG 1
+#ifndef PTX_STRIPES
+#define PTX_STRIPES 4u  // counters of a launch's work cursor (a power of two, at most 8: CURSOR_WORDS); 4 / 8: a 4 M-ray launch on cornell 119 / 153 us, the scenes equal
 #endif
 #ifndef PTX_GRAB
 #define PTX_GRAB 2u  // windows per atomic in launches of up to PTX_STATIC_UPTO windows per wave
@@ -300,7 +300,9 @@ constexpr uint32_t TRI_BATCH_ANYHIT = PTX_TRI_BATCH_ANY;
 #ifndef PTX_AUTO_MEMORY_FRACTION
 #define PTX_AUTO_MEMORY_FRACTION 0.5
 #endif
-constexpr int CURSOR_WORDS = 8;  // a launch's work cursor has 32 bytes to itself (only the first word is used)
+constexpr int CURSOR_STRIDE_WORDS = 32;                  // the counters of a cursor sit on separate 128-byte lines
+constexpr int CURSOR_WORDS = 8 * CURSOR_STRIDE_WORDS;    // a launch's work cursor: 1 KB, zero before the launch
+static_assert(PTX_STRIPES >= 1u && PTX_STRIPES <= 8u && (PTX_STRIPES & (PTX_STRIPES - 1u)) == 0u, "PTX_STRIPES: 1, 2, 4 or 8");
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -368,13 +370,13 @@ __device__ __forceinline__ void st_stream(uint8_t* p, uint8_t v) {
 #endif
 }
 
-// Scratch of ptx_intersect_batch_device_noalloc (include/ptx.h): the launch's work cursor (first 256 bytes) and
+// Scratch of ptx_intersect_batch_device_noalloc (include/ptx.h): the launch's work cursor (first 1024 bytes) and
 // the spill levels of the traversal stacks of NOALLOC_GRID workgroups.  File-scope device memory: every GPU the
 // library runs on holds its own copy at its own address until the process ends.  Host code never uses the
 // array's name as an address: ptx_scene_create asks hipGetSymbolAddress once per device and keeps the pointer.
 constexpr int NOALLOC_GRID = 256;  // workgroups of the allocation-free launch (one per CU)
 constexpr size_t NOALLOC_SPILL_BYTES = (size_t)(PTX_MAX_DEPTH - LDS_DEPTH) * NOALLOC_GRID * TBLOCK * sizeof(uint2);
-constexpr size_t NOALLOC_SCRATCH_BYTES = 256 + NOALLOC_SPILL_BYTES;  // 34.0 MiB
+constexpr size_t NOALLOC_SCRATCH_BYTES = CURSOR_WORDS * sizeof(uint32_t) + NOALLOC_SPILL_BYTES;  // 34.0 MiB
 static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
 
 // The reference walks a ray's whole range [t_min, t_max] - [0, f32::MAX] for the renderer's rays - and so visits, and
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(TBLOCK, 8) void k_traverse(TravArgs a) {
     static_assert((LDS_DEPTH & (LDS_DEPTH - 1)) == 0 && (TBLOCK & (TBLOCK - 1)) == 0, "the ring needs powers of two");
     __shared__ uint2 s_stack[LDS_DEPTH][TBLOCK];
     __shared__ uint4 s_top[TOP_NODES > 0 ? TOP_NODES : 1];
-    __shared__ uint32_t s_dry;  // a wave of this workgroup has found the cursor's pool empty: the others need not ask
+    __shared__ uint32_t s_dry;  // bit c: a wave of this workgroup has found counter c of the cursor dry - the others need not ask
     char* const s_base = reinterpret_cast<char*>(&s_stack[0][0]);
     constexpr uint32_t LVL = TBLOCK * 8u;        // bytes per stack level
     constexpr uint32_t RING = LVL * LDS_DEPTH;   // bytes of the ring
@@ -750,7 +752,8 @@ __global__ __launch_bounds__(TBLOCK, 8) void k_traverse(TravArgs a) {
     uint32_t lo = 0, hi = 0;
     uint32_t windows = 0;  // 2: no window is left for this wave
     uint32_t taken = 0;    // windows this wave has taken by its own number
-    uint32_t pend_next = 0, pend_end = 0;  // windows taken from the cursor several at a time and not yet used
+    uint32_t pend_next = 0, pend_end = 0;  // windows taken from the cursor several at a time and not yet used (PTX_STRIPES apart)
+    uint32_t stripe = __builtin_amdgcn_readfirstlane((blockIdx.x * (TBLOCK / 64) + (tid >> 6)) & (PTX_STRIPES - 1u));  // the counter this wave asks first
     constexpr int32_t DESC_PARKED = -3;  // a ray that waits for the long walk (no leaf descriptor: those end at 0xBFFFFFFD)
     int32_t cur = DESC_IDLE;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, t_end = 0, t1 = 0, t2 = 0;
@@ -832,30 +835,47 @@ __global__ __launch_bounds__(TBLOCK, 8) void k_traverse(TravArgs a) {
                         windows = 2u;
                         break;
                     }
-                    // A launch of a few windows per wave has them all under way at once, and what it then waits for is the
-                    // cursor (a 4 M-ray launch on cornell: 405 us, 393 of them 24 576 atomics; the late-bounce launches of the
-                    // 4K scenes sit on the same floor): there one atomic takes PTX_GRAB windows.  (Large launches keep single
-                    // windows: grabs of remaining / (4 x waves) windows cost cornell_teapot 15 % - the waves then work on
+                    // The cursor is PTX_STRIPES counters, one 128-byte line each: counter c hands out the windows c, c + STRIPES,
+                    // c + 2 STRIPES ... of the pool.  Atomics on one line complete 11 ns apart however many waves issue them, and
+                    // counters on separate lines do so independently (tools/atomic_probe.hip: 8 counters, 1.5 ns per atomic) -
+                    // while the windows under way at any time stay neighbours in the queue, as with one counter.  A wave starts at
+                    // counter wave % STRIPES and, when that one has run dry, goes on to the next; a workgroup keeps the set of dry
+                    // counters in LDS, so that the last, failing atomic of a counter is paid once per workgroup and not once per
+                    // wave.  A launch of a few windows per wave (all of them under way at once; a 4 M-ray launch on cornell took
+                    // 405 us, 393 of them the single cursor's) takes PTX_GRAB windows of a counter per atomic.  (Large launches keep
+                    // single windows: grabs of remaining / (4 x waves) windows cost cornell_teapot 15 % - the waves then work on
                     // distant parts of the queue at the same time and share less of the tree in the L2.)
                     if (pend_next < pend_end) {
-                        w = pend_next++;
+                        w = pend_next;
+                        pend_next += PTX_STRIPES;
                     } else {
-                        // (the last atomic of a wave finds nothing: 8192 of them, ~16 ns apiece, at the end of every launch -
-                        // the first wave of a workgroup to see the pool empty says so, and the other fifteen do not ask)
-                        if (PTX_DRY_FLAG && *(volatile uint32_t*)&s_dry) {
-                            windows = 2u;
-                            break;
-                        }
+                        const uint32_t pool = n_windows - n_static;
                         const uint32_t g = per_wave <= PTX_STATIC_UPTO ? PTX_GRAB : 1u;
-                        if (lane == 0) w = atomicAdd(ka->cursor, g);
-                        w = __builtin_amdgcn_readfirstlane(w) + n_static;
-                        if (w >= n_windows) {
-                            if (PTX_DRY_FLAG && lane == 0) *(volatile uint32_t*)&s_dry = 1u;
+                        uint32_t dry = *(volatile uint32_t*)&s_dry;
+                        bool found = false;
+                        for (uint32_t tries = 0; tries < PTX_STRIPES && !found; ++tries) {
+                            const uint32_t c = (stripe + tries) & (PTX_STRIPES - 1u);
+                            if ((dry >> c) & 1u) continue;
+                            uint32_t unit = 0;
+                            if (lane == 0) unit = atomicAdd(ka->cursor + c * CURSOR_STRIDE_WORDS, g);
+                            unit = __builtin_amdgcn_readfirstlane(unit);
+                            const uint32_t first = unit * PTX_STRIPES + c;  // its place in the pool
+                            if (first >= pool) {
+                                dry |= 1u << c;
+                                if (lane == 0) atomicOr(&s_dry, 1u << c);
+                                continue;
+                            }
+                            found = true;
+                            stripe = c;
+                            w = first + n_static;
+                            const uint32_t stop = (unit + g) * PTX_STRIPES < pool ? (unit + g) * PTX_STRIPES : pool;
+                            pend_next = w + PTX_STRIPES;
+                            pend_end = stop + n_static;
+                        }
+                        if (!found) {
                             windows = 2u;
                             break;
                         }
-                        pend_next = w + 1u;
-                        pend_end = w + g < n_windows ? w + g : n_windows;
                     }
                 }
                 const bool large = w < n_a;
@@ -2350,7 +2370,7 @@ int ptx_intersect_batch_device_noalloc(ptx_scene* sc, const ptx_ray* d_rays, siz
     ++sc->extend_launches;
     HIP_TRY(hipMemsetAsync(ptr, 0, CURSOR_WORDS * sizeof(uint32_t), (hipStream_t)stream));  // the cursors must start at zero
     return launch_traverse<false>(sc, d_rays, SegRange{}, (uint32_t)n, d_hits, nullptr, reinterpret_cast<uint32_t*>(ptr),
-                                  reinterpret_cast<uint2*>(ptr + 256), sc->totals.p + 2, (hipStream_t)stream, NOALLOC_GRID);
+                                  reinterpret_cast<uint2*>(ptr + CURSOR_WORDS * sizeof(uint32_t)), sc->totals.p + 2, (hipStream_t)stream, NOALLOC_GRID);
 }
 
 int ptx_occluded_batch_device(ptx_scene* sc, const ptx_ray* d_rays, size_t n, uint8_t* d_out, void* stream) {
@@ -2655,10 +2675,11 @@ static int render_impl(ptx_scene* sc, const ptx_pinhole* cam, uint64_t seed, uin
                         uint32_t h[2][8];
                         (void)hipMemcpy(h[0], plan_ext, 32, hipMemcpyDeviceToHost);
                         (void)hipMemcpy(h[1], plan_sh, 32, hipMemcpyDeviceToHost);
-                        uint32_t cur[16];
-                        (void)hipMemcpy(cur, st.cursors + 2 * CURSOR_WORDS * (b - 1), 64, hipMemcpyDeviceToHost);
+                        uint32_t cur[2];  // (the first counter of each cursor)
+                        (void)hipMemcpy(&cur[0], st.cursors + 2 * CURSOR_WORDS * (b - 1), 4, hipMemcpyDeviceToHost);
+                        (void)hipMemcpy(&cur[1], st.cursors + 2 * CURSOR_WORDS * (b - 1) + CURSOR_WORDS, 4, hipMemcpyDeviceToHost);
                         fprintf(stderr, "[plan] round %u: next-extend chunk %u large %u small %u tail_num %u | shadow chunk %u large %u small %u tail_num %u | cursors ext %u sh %u (n_waves %u)\n",
-                                b, h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3], cur[0], cur[8], n_waves);
+                                b, h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3], cur[0], cur[1], n_waves);
                     }
                     if (sc->flags & PTX_FLAG_CHECK_BRUTE) launch_check(sc, st.sh_rays, sr, nullptr, st.sh_occ, sstream);
                     if (sc->raylog_cap) k_log<true><<<(int)n_seg, BLOCK, 0, sstream>>>(st, LogArgs{sc->raylog.p, sc->raylog_count.p, sc->raylog_cap}, 0u, L);
