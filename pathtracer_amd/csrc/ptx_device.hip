@@ -262,10 +262,10 @@ constexpr uint32_t TRI_BATCH_ANYHIT = PTX_TRI_BATCH_ANY;
 #define PTX_TAIL_ROUNDS 2u  // 64-ray windows per wave handed out after the large ones
 #endif
 #ifndef PTX_MAX_CHUNK
-#define PTX_MAX_CHUNK 1024u  // largest window of a nearest-hit launch
+#define PTX_MAX_CHUNK 512u  // largest window of a nearest-hit launch (1024 while the cursor was one counter: see win_shape)
 #endif
 #ifndef PTX_MAX_CHUNK_ANY
-#define PTX_MAX_CHUNK_ANY 512u  // ... of an any-hit launch
+#define PTX_MAX_CHUNK_ANY 256u  // ... of an any-hit launch
 #endif
 #ifndef PTX_SHADE_WAVES
 #define PTX_SHADE_WAVES 1  // minimum waves per SIMD the register allocation of k_shade must allow
@@ -428,9 +428,11 @@ __device__ __forceinline__ bool box_clip(float ox, float oy, float oz, float dx,
 struct WinShape {
     uint32_t chunk, tail_num;  // tail_num / 65536 = share of every segment that goes out in 64-ray windows
 };
-// The largest window differs by kind (round 3, sr2 3840x2160 where nine camera rays in ten miss the scene's box and
-// retire at once: its extend launches are bound by the cursor, 512 rays per ~16 ns = 32 Grays/s, and 1024-ray windows
-// take 19 % off them; the any-hit launches lose 3 % with 1024 and cornell_teapot's extend does not care).
+// The largest window differs by kind.  While the cursor was ONE counter (one window per 11-16 ns) large windows were what kept
+// it off the critical path: 1024 rays for nearest-hit launches (sr2 3840x2160: -19 % against 512), 512 for any-hit ones.
+// With the striped cursor (v31) smaller windows even the launches out again: 1024 / 512 -> 512 / 256: sr2 +3.1 %,
+// cubesplosion +1.3 %, cornell_teapot +1.6 %, cornell_textured +0.4 %; 256 / 256: sr2 +4.2 %, cubesplosion +2.2 %,
+// cornell_teapot -0.6 %, cornell_textured -1.1 % (profiles/r03_loop_variants.txt 18).
 __device__ inline WinShape win_shape(unsigned long long total_rays, uint32_t n_waves, bool any_hit) {
     const unsigned long long est = total_rays / (n_waves * 4ull);
     const uint32_t max_chunk = any_hit ? PTX_MAX_CHUNK_ANY : PTX_MAX_CHUNK;
