@@ -261,6 +261,9 @@ constexpr uint32_t TRI_BATCH_ANYHIT = PTX_TRI_BATCH_ANY;
 #ifndef PTX_TAIL_ROUNDS
 #define PTX_TAIL_ROUNDS 2u  // 64-ray windows per wave handed out after the large ones
 #endif
+#ifndef PTX_WINDOWS_PER_WAVE
+#define PTX_WINDOWS_PER_WAVE 4u  // a launch's windows are sized so that a wave gets about this many (up to PTX_MAX_CHUNK rays each)
+#endif
 #ifndef PTX_MAX_CHUNK
 #define PTX_MAX_CHUNK 512u  // largest window of a nearest-hit launch (1024 while the cursor was one counter: see win_shape)
 #endif
@@ -434,7 +437,7 @@ struct WinShape {
 // cubesplosion +1.3 %, cornell_teapot +1.6 %, cornell_textured +0.4 %; 256 / 256: sr2 +4.2 %, cubesplosion +2.2 %,
 // cornell_teapot -0.6 %, cornell_textured -1.1 % (profiles/r03_loop_variants.txt 18).
 __device__ inline WinShape win_shape(unsigned long long total_rays, uint32_t n_waves, bool any_hit) {
-    const unsigned long long est = total_rays / (n_waves * 4ull);
+    const unsigned long long est = total_rays / (n_waves * (unsigned long long)PTX_WINDOWS_PER_WAVE);
     const uint32_t max_chunk = any_hit ? PTX_MAX_CHUNK_ANY : PTX_MAX_CHUNK;
     WinShape ws{64u, 0u};
     while (ws.chunk < max_chunk && 2ull * ws.chunk <= est) ws.chunk *= 2u;
