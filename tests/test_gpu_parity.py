@@ -426,3 +426,33 @@ def test_scene_with_split_planes_outside_the_short_division_window():
     dev.close()
     assert_hits_equal(got, want)
     assert (got["index"] != pt.MISS).mean() > 0.2
+
+
+def test_every_ray_is_answered_exactly_once_at_any_launch_size():
+    """The windows of a traversal launch are handed out by number, from four striped counters, one or two at a time
+    (k_traverse's refill): whatever the ray count, every ray gets its answer, no slot beyond the last ray is written,
+    and the occlusion query agrees - from one ray to a few million, on sizes that leave partial windows, partial stripes
+    and partial pairs."""
+    import torch
+
+    path = os.path.join(SCENES, "cornell_teapot.obj")
+    ref = orc.Scene(path)
+    tris = ref.export()["triangles"].reshape(-1, 3, 3)
+    rays = synthetic_rays(tris.min((0, 1)), tris.max((0, 1)), 1 << 22, 0x5EED000A)[: (1 << 22) + 13]
+    want = ref.tree().intersect(rays, threads=8)
+    dev = pt.LoadedScene(path).upload()
+    d_rays = torch.from_numpy(rays.view(np.uint8).copy()).cuda()
+    sentinel = np.uint8(0xA5)
+    for n in (1, 63, 64, 65, 1000, 65537, 300001, (1 << 20) + 1, (1 << 21) + 7, (1 << 22) + 13):
+        d_hits = torch.full(((len(rays) + 1) * 16,), int(sentinel), dtype=torch.uint8, device="cuda")
+        d_occ = torch.full((len(rays) + 1,), int(sentinel), dtype=torch.uint8, device="cuda")
+        dev.intersect_device(d_rays.data_ptr(), n, d_hits.data_ptr())
+        dev.occluded_device(d_rays.data_ptr(), n, d_occ.data_ptr())
+        torch.cuda.synchronize()
+        got = d_hits.cpu().numpy()
+        assert got[: n * 16].tobytes() == want[:n].tobytes(), n
+        assert (got[n * 16:] == sentinel).all(), n
+        occ = d_occ.cpu().numpy()
+        assert (occ[:n].astype(bool) == (want[:n]["index"] != pt.MISS)).all(), n
+        assert (occ[n:] == sentinel).all(), n
+    dev.close()
